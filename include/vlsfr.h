@@ -1,0 +1,114 @@
+/*
+ * vlsfr.h — C-ABI of libvlsfr.so: the MI355X-native (gfx950) FFC training hot path.
+ *
+ * The reference (sqnkkang/Very-Large-Scale-Face-Recognition) is 100 % Python/PyTorch and has no
+ * FFI of its own; its boundary for this path is the Python module API
+ * (ffc.FFC / lru.LRU / model.create_net / optim.get_optim_scheduler).  The build's Python mirror
+ * of that API (the .py modules of very-large-scale-face-recognition_amd/) binds the entry points below through
+ * ctypes on tensor.data_ptr(); INTEGRATION.md shows the stub.  Every entry point names the
+ * reference lines it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative VLSFR_E* code on failure;
+ *     vlsfr_last_error() returns a thread-local message for the last failure.
+ *   - device buffers are caller-owned (PyTorch-allocated); no hidden allocation, no hidden
+ *     synchronisation; every device entry point takes an explicit hipStream_t (as void*).
+ *   - workspaces are sized by the matching *_workspace_bytes() query.
+ *   - plain pointers and sizes only — no torch types.
+ */
+#ifndef VLSFR_H
+#define VLSFR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLSFR_OK 0
+#define VLSFR_EINVAL (-1)   /* bad argument / shape the kernel does not cover            */
+#define VLSFR_ESTATE (-2)   /* call not legal in the handle's current state (assert in ref) */
+#define VLSFR_EHIP (-3)     /* a HIP runtime call failed                                 */
+#define VLSFR_ENOMEM (-4)
+
+const char* vlsfr_last_error(void);
+int vlsfr_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 1. LRU slot allocator (host).  Replaces lru.py:21-255 (class LRU).
+ *    Keys are int64 identity labels, values are int32 pool slots.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_lru vlsfr_lru;
+
+/* lru.py:27-40 */
+int vlsfr_lru_create(int64_t capacity, vlsfr_lru** out);
+void vlsfr_lru_destroy(vlsfr_lru* h);
+/* lru.py:44-89  LRU.get — committing lookup/insert/evict; *slot receives the value */
+int vlsfr_lru_get(vlsfr_lru* h, int64_t key, int32_t* slot);
+/* lru.py:157-204 LRU.try_get — same, and pushes an undo record on the op stack */
+int vlsfr_lru_try_get(vlsfr_lru* h, int64_t key, int32_t* slot);
+/* lru.py:147-151 LRU.view — slot or -1, never reorders */
+int vlsfr_lru_view(const vlsfr_lru* h, int64_t key, int32_t* slot);
+/* lru.py:145 LRU.__contains__ — returns 1/0 */
+int vlsfr_lru_contains(const vlsfr_lru* h, int64_t key);
+/* lru.py:210-255 rollback_one_step / rollback_steps — clamped to the stack depth; returns the
+ * number of steps actually undone in *undone (may be NULL) */
+int vlsfr_lru_rollback(vlsfr_lru* h, int64_t steps, int64_t* undone);
+/* lru.py:102-108 state_dict — MRU→LRU (key, slot) pairs; n_max = capacity of the out arrays;
+ * *n receives the number of entries */
+int vlsfr_lru_state(const vlsfr_lru* h, int64_t* keys, int32_t* slots, int64_t n_max, int64_t* n);
+/* lru.py:113-128 restore — requires cur_idx == 0 and n <= capacity and distinct keys
+ * (VLSFR_ESTATE otherwise, the reference asserts) */
+int vlsfr_lru_restore(vlsfr_lru* h, const int64_t* keys, const int32_t* slots, int64_t n);
+/* lru.py:132-141 clear — empties list and map, does NOT reset cur_idx (reference behaviour) */
+int vlsfr_lru_clear(vlsfr_lru* h);
+/* public fields lru.py:28-30,40: capacity, cur_idx, len(cache), len(op_stack) */
+int64_t vlsfr_lru_capacity(const vlsfr_lru* h);
+int64_t vlsfr_lru_cur_idx(const vlsfr_lru* h);
+int64_t vlsfr_lru_size(const vlsfr_lru* h);
+int64_t vlsfr_lru_op_depth(const vlsfr_lru* h);
+/* op-stack type names for op_stack[i].op_type: 0 = 'Add', 1 = 'Overflow', 2 = 'Get' */
+int vlsfr_lru_op_type(const vlsfr_lru* h, int64_t i);
+
+/* ------------------------------------------------------------------------------------------
+ * 2. Dynamic-Class-Pool bookkeeping for one FFC pass (host).
+ *    Replaces the Python loops of ffc.py:162-177 / 189-192 (forward_impl) and
+ *    ffc.py:214-235 / 242-245 / 256-259 (forward_impl_rollback): gallery labels → (row, slot)
+ *    write list, probe labels → pool labels, ones_idx, queue_position_dict toggling.
+ *
+ *    qp is the reference's queue_position_dict as a uint8[capacity] array owned by the caller.
+ *    transactional != 0 selects try_get + old_state semantics; vlsfr_dcp_undo() then restores
+ *    qp and rolls the LRU back (ffc.py:256-259).
+ *
+ *    Besides the reference's outputs the call emits the "special column" table the fused head
+ *    kernel consumes: the pool slots whose logits cannot be taken from an
+ *    unmodified sweep over queue[0] — slots written in this pass, slots in ones_idx, and the
+ *    probe rows' label slots.  For special column s, src1[s] / src2[s] say where the class
+ *    vector of the cos_theta1 / cos_theta2 contraction (ffc.py:195,201 / 248,253) comes from:
+ *        >= 0 : row i of this pass's gallery embeddings g (last writer wins)
+ *        -1   : queue[0][slot] as stored      -2 : queue[1][slot] as stored
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_dcp_plan {
+  int32_t n;          /* batch rows B                                                        */
+  int32_t n_ones;     /* |ones_idx|                                                          */
+  int32_t n_special;  /* number of special columns (<= 3B)                                   */
+  int32_t n_pos;      /* probe rows with label != -1                                         */
+  int32_t n_undo;     /* transactional: number of qp entries saved                           */
+  int32_t steps;      /* transactional: LRU steps to roll back (== n)                        */
+} vlsfr_dcp_plan;
+
+int vlsfr_dcp_assign(vlsfr_lru* h, uint8_t* qp, const int64_t* gallery_label,
+                     const int64_t* probe_label, int32_t n, int transactional,
+                     int32_t* rows /*[n]*/, int32_t* cols /*[n]*/, int32_t* pool_label /*[n]*/,
+                     int32_t* ones_idx /*[n]*/, int32_t* special_col /*[3n]*/,
+                     int32_t* src1 /*[3n]*/, int32_t* src2 /*[3n]*/,
+                     int32_t* undo_slot /*[n]*/, uint8_t* undo_val /*[n]*/,
+                     vlsfr_dcp_plan* plan);
+int vlsfr_dcp_undo(vlsfr_lru* h, uint8_t* qp, const int32_t* undo_slot, const uint8_t* undo_val,
+                   const vlsfr_dcp_plan* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLSFR_H */

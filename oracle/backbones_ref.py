@@ -1,0 +1,183 @@
+"""ORACLE — test infrastructure only (never imported by the product package).
+
+CPU restatement (plain PyTorch CPU ops, fp32 or fp64) of the two backbones on the FFC hot path,
+driven by a flat state dict that uses the reference's parameter names:
+  * iResNet      — reference model/resnet_arcface.py:26-55 (IBasicBlock), :58-152 (IResNet)
+  * MobileFaceNet — reference model/mobilefacenet_def.py:18-25, :27-52, :55-74, :77-123
+Both run in training mode (batch statistics, running-stat update with momentum 0.1, eps 1e-5),
+because the reference never calls .eval() on either net (ffc.py:22-23, main.py:116-121).
+
+Pinned against the reference itself: tests/golden/backbone_*.npz were produced by importing the
+reference modules in the build container (tests/golden/make_golden.py).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+IRESNET_LAYERS = {"ir18": (2, 2, 2, 2), "ir34": (3, 4, 6, 3), "ir50": (3, 4, 14, 3), "ir100": (3, 13, 30, 3),
+                  "ir200": (6, 26, 60, 6)}
+MOBILE_SETTING = ((2, 64, 5, 2), (4, 128, 1, 2), (2, 128, 6, 1), (4, 128, 1, 2), (2, 128, 2, 1))
+
+
+# ----------------------------------------------------------------------------------------------
+# state-dict construction (names/shapes/initial distributions of the reference constructors)
+# ----------------------------------------------------------------------------------------------
+def _bn(sd, name, c):
+    sd[name + ".weight"] = torch.ones(c)
+    sd[name + ".bias"] = torch.zeros(c)
+    sd[name + ".running_mean"] = torch.zeros(c)
+    sd[name + ".running_var"] = torch.ones(c)
+    sd[name + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+
+def _uniform(shape, bound, gen):
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+def iresnet_state(layers, feat_dim=512, gen=None):
+    """resnet_arcface.py:74-105: conv ~ N(0, 0.1), BN 1/0, PReLU 0.25, Linear default init."""
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=gen) * 0.1
+
+    conv("conv1", 64, 3, 3)
+    _bn(sd, "bn1", 64)
+    sd["prelu.weight"] = torch.full((64,), 0.25)
+    cin = 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), layers), start=1):
+        for bi in range(nblk):
+            pre = "layer%d.%d" % (li, bi)
+            _bn(sd, pre + ".bn1", cin)
+            conv(pre + ".conv1", planes, cin, 3)
+            _bn(sd, pre + ".bn2", planes)
+            sd[pre + ".prelu.weight"] = torch.full((planes,), 0.25)
+            conv(pre + ".conv2", planes, planes, 3)
+            _bn(sd, pre + ".bn3", planes)
+            if bi == 0:
+                conv(pre + ".downsample.0", planes, cin, 1)
+                _bn(sd, pre + ".downsample.1", planes)
+            cin = planes
+    _bn(sd, "bn2", 512)
+    fan_in = 512 * 49
+    sd["fc.weight"] = _uniform((feat_dim, fan_in), 1.0 / math.sqrt(fan_in), gen)
+    sd["fc.bias"] = _uniform((feat_dim,), 1.0 / math.sqrt(fan_in), gen)
+    _bn(sd, "features", feat_dim)
+    return sd
+
+
+def mobilefacenet_state(feat_dim=128, gen=None):
+    """mobilefacenet_def.py:77-102: nn.Conv2d default init (kaiming-uniform a=sqrt 5 ⇒ U(±1/sqrt(fan_in)))."""
+    sd = {}
+
+    def convblock(name, ci, co, k, dw=False, linear=False):
+        fan_in = (1 if dw else ci) * k * k
+        sd[name + ".conv.weight"] = _uniform((co, 1 if dw else ci, k, k), 1.0 / math.sqrt(fan_in), gen)
+        _bn(sd, name + ".bn", co)
+        if not linear:
+            sd[name + ".prelu.weight"] = torch.full((co,), 0.25)
+
+    convblock("conv1", 3, 64, 3)
+    convblock("dw_conv1", 64, 64, 3, dw=True)
+    cur, bi = 64, 0
+    for t, c, n, s in MOBILE_SETTING:
+        for i in range(n):
+            pre = "blocks.%d.conv" % bi
+            mid = cur * t
+            sd[pre + ".0.weight"] = _uniform((mid, cur, 1, 1), 1.0 / math.sqrt(cur), gen)
+            _bn(sd, pre + ".1", mid)
+            sd[pre + ".2.weight"] = torch.full((mid,), 0.25)
+            sd[pre + ".3.weight"] = _uniform((mid, 1, 3, 3), 1.0 / 3.0, gen)
+            _bn(sd, pre + ".4", mid)
+            sd[pre + ".5.weight"] = torch.full((mid,), 0.25)
+            sd[pre + ".6.weight"] = _uniform((c, mid, 1, 1), 1.0 / math.sqrt(mid), gen)
+            _bn(sd, pre + ".7", c)
+            cur = c
+            bi += 1
+    convblock("conv2", 128, 512, 1)
+    convblock("linear7", 512, 512, 7, dw=True, linear=True)
+    convblock("linear1", 512, feat_dim, 1, linear=True)
+    return sd
+
+
+def is_buffer(name):
+    return name.endswith("running_mean") or name.endswith("running_var") or name.endswith("num_batches_tracked")
+
+
+def trainable(name):
+    """resnet_arcface.py:97-98 freezes features.weight; buffers never train."""
+    return not is_buffer(name) and name != "features.weight"
+
+
+# ----------------------------------------------------------------------------------------------
+# forward passes (training-mode BN; running stats updated in place in `sd`)
+# ----------------------------------------------------------------------------------------------
+def _bn_train(sd, name, x):
+    rm, rv = sd[name + ".running_mean"], sd[name + ".running_var"]
+    y = F.batch_norm(x, rm, rv, sd[name + ".weight"], sd[name + ".bias"], True, 0.1, 1e-5)
+    sd[name + ".num_batches_tracked"] += 1
+    return y
+
+
+def iresnet_forward(sd, x, layers):
+    h = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
+    h = F.prelu(_bn_train(sd, "bn1", h), sd["prelu.weight"])
+    for li, nblk in enumerate(layers, start=1):
+        for bi in range(nblk):
+            pre = "layer%d.%d" % (li, bi)
+            stride = 2 if bi == 0 else 1
+            o = _bn_train(sd, pre + ".bn1", h)
+            o = F.conv2d(o, sd[pre + ".conv1.weight"], None, 1, 1)
+            o = F.prelu(_bn_train(sd, pre + ".bn2", o), sd[pre + ".prelu.weight"])
+            o = F.conv2d(o, sd[pre + ".conv2.weight"], None, stride, 1)
+            o = _bn_train(sd, pre + ".bn3", o)
+            if bi == 0:
+                idn = F.conv2d(h, sd[pre + ".downsample.0.weight"], None, stride, 0)
+                idn = _bn_train(sd, pre + ".downsample.1", idn)
+            else:
+                idn = h
+            h = o + idn
+    h = _bn_train(sd, "bn2", h)
+    h = torch.flatten(h, 1)
+    h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
+    h = _bn_train(sd, "features", h)
+    return F.normalize(h)
+
+
+def mobilefacenet_forward(sd, x):
+    def convblock(name, h, stride, pad, dw=False, linear=False):
+        w = sd[name + ".conv.weight"]
+        h = F.conv2d(h, w, None, stride, pad, 1, w.shape[0] if dw else 1)
+        h = _bn_train(sd, name + ".bn", h)
+        return h if linear else F.prelu(h, sd[name + ".prelu.weight"])
+
+    h = convblock("conv1", x, 2, 1)
+    h = convblock("dw_conv1", h, 1, 1, dw=True)
+    cur, bi = 64, 0
+    for t, c, n, s in MOBILE_SETTING:
+        for i in range(n):
+            pre = "blocks.%d.conv" % bi
+            stride = s if i == 0 else 1
+            o = F.conv2d(h, sd[pre + ".0.weight"])
+            o = F.prelu(_bn_train(sd, pre + ".1", o), sd[pre + ".2.weight"])
+            w = sd[pre + ".3.weight"]
+            o = F.conv2d(o, w, None, stride, 1, 1, w.shape[0])
+            o = F.prelu(_bn_train(sd, pre + ".4", o), sd[pre + ".5.weight"])
+            o = F.conv2d(o, sd[pre + ".6.weight"])
+            o = _bn_train(sd, pre + ".7", o)
+            h = h + o if (stride == 1 and cur == c) else o
+            cur = c
+            bi += 1
+    h = convblock("conv2", h, 1, 0)
+    h = convblock("linear7", h, 1, 0, dw=True, linear=True)
+    h = convblock("linear1", h, 1, 0, linear=True)
+    return F.normalize(torch.flatten(h, 1))
+
+
+def make_backbone(net_type, feat_dim, gen=None, layers=None):
+    """Returns (state_dict, forward(sd, x))."""
+    if net_type == "mobile":
+        return mobilefacenet_state(feat_dim, gen), mobilefacenet_forward
+    lay = tuple(layers) if layers is not None else IRESNET_LAYERS[net_type]
+    return iresnet_state(lay, feat_dim, gen), (lambda sd, x: iresnet_forward(sd, x, lay))
