@@ -108,6 +108,53 @@ int vlsfr_dcp_assign(vlsfr_lru* h, uint8_t* qp, const int64_t* gallery_label,
 int vlsfr_dcp_undo(vlsfr_lru* h, uint8_t* qp, const int32_t* undo_slot, const uint8_t* undo_val,
                    const vlsfr_dcp_plan* plan);
 
+/* ------------------------------------------------------------------------------------------
+ * 3. Pool rows (device).  Replaces `self.queue[r, c] = g` (ffc.py:182; the transient write and
+ *    restore of ffc.py:240-241,255 are not needed: the rollback pass never mutates the pool).
+ *    queue: fp32 [2, Q, D] row-major; duplicate (row, col): the highest batch index wins.
+ * ---------------------------------------------------------------------------------------- */
+int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g /*[n, D]*/,
+                       const int32_t* rows /*[n] dev*/, const int32_t* cols /*[n] dev*/, int32_t n,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Fused DCP head (device): loss and dL/dp of one FFC pass in one sweep over queue[0].
+ *    Replaces F.linear x2 + mask blend + add_margin x2 and their backward
+ *    (ffc.py:195-203 / 248-258, ffc.py:60-138).
+ *    loss_type: 0 'AM', 1 'Arc', 2 'SV' (ffc.py:17).  precise != 0 selects split-bf16 (hi + lo)
+ *    MFMA products (~fp32 accuracy, parity mode); 0 = plain bf16 MFMA operands, fp32 accumulate.
+ *    n_chunks = 0 lets the library choose the column partition.
+ *    Device inputs: p, g fp32 [B, D]; queue fp32 [2, Q, D]; pool_label int32 [B] (slot or -1);
+ *    special_col/src1/src2 int32 [n_special] from vlsfr_dcp_assign.
+ *    Device outputs: loss_out fp32 [1] (= add_margin(cos_theta1) + add_margin(cos_theta2)),
+ *    dP fp32 [B, D] (= d loss / d p against the pool as it stands at call time).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_head_cfg {
+  int32_t B;
+  int32_t D;
+  int64_t Q;
+  int32_t loss_type;
+  float scale;
+  float margin;
+  int32_t hard_neg;
+  int32_t precise;
+  int32_t n_chunks;
+} vlsfr_head_cfg;
+
+size_t vlsfr_head_workspace_bytes(const vlsfr_head_cfg* cfg);
+int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                       const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                       const int32_t* src2, int32_t n_special, int32_t n_pos, float* loss_out, float* dP,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 0. Hardware-convention probes (device, test support): one-wave kernels that pin the MFMA
+ *    16x16x32 bf16 fragment maps and the ds_read_b64_tr_b16 transposed read the kernels use.
+ *    A [16,32], B [32,16] / Bt [16,32], C [16,16], all fp32 device buffers.
+ * ---------------------------------------------------------------------------------------- */
+int vlsfr_probe_mfma_tr(const float* A, const float* B, float* C, int32_t row_stride_bytes, void* stream);
+int vlsfr_probe_mfma_nat(const float* A, const float* Bt, float* C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,169 @@
+"""GPU parity of the fused DCP head (through the C-ABI) against the reference's golden vectors, the
+oracle on seeded inputs, and size-independent properties at the 1M-identity configuration."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ffc_ref
+from oracle.lru_ref import LRURef
+from tests.golden import common
+from tests.test_oracle_golden import HEAD_FILES, load_head_case
+
+pytestmark = pytest.mark.gpu
+
+# Tolerances (stated per SURVEY §8d): "precise" = split-bf16 MFMA products (~2^-16 relative per
+# product) -> fp32-class agreement; plain bf16 operands -> 2^-9 relative per product.
+TOL = {True: dict(loss_rtol=2e-5, loss_atol=2e-5, dp_rtol=1e-3, dp_atol=2e-5),
+       False: dict(loss_rtol=3e-3, loss_atol=3e-3, dp_rtol=5e-2, dp_atol=1e-2)}
+
+
+def make_head(queue0, loss_type, scale, margin, precise, n_chunks=0):
+    from vlsfr_amd.head import DcpHead
+    q = torch.from_numpy(queue0).cuda().contiguous()
+    return DcpHead(q, scale, margin, loss_type, precise=precise, n_chunks=n_chunks)
+
+
+@pytest.mark.parametrize("precise", [True, False])
+@pytest.mark.parametrize("fname", HEAD_FILES)
+def test_head_matches_reference_golden(fname, precise):
+    case, (Q, D, B, T, hard_neg), loss_type, scale, margin = load_head_case(fname)
+    head = make_head(case["queue0"], loss_type, scale, margin, precise)
+    assert head.hard_neg == hard_neg
+    tol = TOL[precise]
+    for t in range(T):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            p = torch.from_numpy(case["P"][t, s]).cuda().requires_grad_(True)
+            g = torch.from_numpy(case["G"][t, s]).cuda()
+            loss = head.run_pass(p, g, pl, gl, trans)
+            loss.backward()
+            np.testing.assert_allclose(float(loss), case["loss"][t, s], rtol=tol["loss_rtol"], atol=tol["loss_atol"],
+                                       err_msg="%s t=%d pass=%d" % (fname, t, s))
+            np.testing.assert_allclose(p.grad.cpu().numpy(), case["dP"][t, s], rtol=tol["dp_rtol"],
+                                       atol=tol["dp_atol"] * max(1.0, np.abs(case["dP"][t, s]).max()),
+                                       err_msg="%s t=%d pass=%d" % (fname, t, s))
+    torch.cuda.synchronize()
+    st = head.lru.state_dict()
+    assert [k for k, _ in st] == case["lru_keys"].tolist()
+    assert [v for _, v in st] == case["lru_slots"].tolist()
+    assert head.qp.tolist() == case["qp"].tolist()
+    qf = head.queue.cpu().numpy()
+    if "queue_final" in case:
+        np.testing.assert_array_equal(qf, case["queue_final"])      # pool rows are bitwise copies of g
+    else:
+        np.testing.assert_array_equal(qf[:, case["touched"]], case["queue_touched"])
+
+
+def oracle_pass(queue, lru, qp, p, g, pl, gl, trans, loss_type, scale, margin, hard_neg):
+    pt = torch.from_numpy(p).double().requires_grad_(True)
+    loss, _ = ffc_ref.head_pass_ref(queue, lru, qp, pt, torch.from_numpy(g).double(), pl.tolist(), gl.tolist(), trans,
+                                    loss_type, scale, margin, hard_neg)
+    loss.backward()
+    return float(loss.detach()), pt.grad.numpy()
+
+
+@pytest.mark.parametrize("loss_type,margin", [("Arc", 0.5), ("AM", 0.4), ("SV", 0.35)])
+@pytest.mark.parametrize("Q,D,B,n_id", [(5000, 128, 64, 4000), (3001, 512, 40, 9000), (70000, 512, 96, 50000)])
+def test_head_vs_oracle_seeded(loss_type, margin, Q, D, B, n_id):
+    """Larger pools, ragged Q (not a multiple of the 32-column tile), B not a multiple of 16 / above
+    one 64-row block, outlier rows (n_id > Q) — against the float64 oracle."""
+    T = 3
+    case = common.head_case(1000 + Q + B, Q, D, B, T, n_id)
+    for precise in (True, False):
+        tol = TOL[precise]
+        head = make_head(case["queue0"], loss_type, 32.0, margin, precise)
+        queue = torch.from_numpy(case["queue0"]).double()
+        lru, qp = LRURef(Q), [0] * Q
+        for t in range(T):
+            xl, yl = case["XL"][t], case["YL"][t]
+            for s, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+                want_loss, want_dp = oracle_pass(queue, lru, qp, case["P"][t, s], case["G"][t, s], pl, gl, trans,
+                                                 loss_type, 32.0, margin, head.hard_neg)
+                p = torch.from_numpy(case["P"][t, s]).cuda().requires_grad_(True)
+                loss = head.run_pass(p, torch.from_numpy(case["G"][t, s]).cuda(), pl, gl, trans)
+                loss.backward()
+                np.testing.assert_allclose(float(loss), want_loss, rtol=tol["loss_rtol"], atol=tol["loss_atol"])
+                np.testing.assert_allclose(p.grad.cpu().numpy(), want_dp, rtol=tol["dp_rtol"],
+                                           atol=tol["dp_atol"] * max(1.0, np.abs(want_dp).max()))
+        assert head.lru.state_dict() == lru.state_dict()
+        assert head.qp.tolist() == qp
+        np.testing.assert_array_equal(head.queue.cpu().numpy(), queue.float().numpy())
+
+
+def test_head_full_size_properties():
+    """BASELINE config C2 head: Q = 1M identities, D = 512, B = 64.  The oracle does not finish in
+    seconds here, so check size-independent properties: (1) the result does not depend on the
+    column partition (n_chunks), (2) the rollback pass leaves pool, LRU and queue_position state
+    bit-identical, (3) everything is finite.  test_head_dense_torch_reference_1m adds a dense fp32
+    evaluation of the same configuration."""
+    from vlsfr_amd.head import DcpHead
+    Q, D, B = 1 << 20, 512, 64
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    queue0 = torch.nn.functional.normalize(torch.randn(2, Q, D, device="cuda", generator=gen), dim=2)
+
+    def run(n_chunks):
+        rng = np.random.default_rng(3)
+        head = DcpHead(queue0.clone(), 32.0, 0.5, "Arc", precise=False, n_chunks=n_chunks)
+        ids = rng.choice(Q * 2, size=B, replace=False).astype(np.int64)
+        warm = rng.choice(Q * 2, size=4096, replace=False).astype(np.int64)
+        warm[:B // 2] = ids[:B // 2]
+        with torch.no_grad():
+            for s in range(0, 4096, 512):   # commit some identities so hits / ones_idx / positives occur
+                w = warm[s:s + 512]
+                head.run_pass(torch.from_numpy(common.unit_rows(rng, 512, D)).cuda(),
+                              torch.from_numpy(common.unit_rows(rng, 512, D)).cuda(), w, w, False)
+        before_q = head.queue.clone()
+        before_lru, before_qp = head.lru._state_arrays(), head.qp.copy()
+        p = torch.from_numpy(common.unit_rows(rng, B, D)).cuda().requires_grad_(True)
+        loss = head.run_pass(p, torch.from_numpy(common.unit_rows(rng, B, D)).cuda(), ids, ids, True)
+        loss.backward()
+        assert torch.equal(head.queue, before_q)
+        after_lru = head.lru._state_arrays()
+        assert np.array_equal(before_lru[0], after_lru[0]) and np.array_equal(before_lru[1], after_lru[1])
+        assert np.array_equal(before_qp, head.qp)
+        return float(loss), p.grad.cpu().numpy()
+
+    l0, d0 = run(0)
+    l1, d1 = run(128)
+    assert np.isfinite(l0) and np.isfinite(d0).all()
+    np.testing.assert_allclose(l0, l1, rtol=1e-4)
+    np.testing.assert_allclose(d0, d1, rtol=2e-2, atol=2e-3 * np.abs(d0).max())
+
+
+def test_head_dense_torch_reference_1m():
+    """Same configuration against a dense fp32 PyTorch evaluation on the GPU (F.linear + CE)."""
+    Q, D, B = 1 << 20, 512, 64
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    queue0 = torch.nn.functional.normalize(torch.randn(2, Q, D, device="cuda", generator=gen), dim=2)
+    from vlsfr_amd.head import DcpHead
+    head = DcpHead(queue0.clone(), 32.0, 0.5, "Arc", precise=False)
+    rng = np.random.default_rng(8)
+    labels = rng.choice(Q, size=B, replace=False).astype(np.int64)
+    # pre-fill the LRU so that label k owns slot k (restore takes MRU->LRU (key, slot) pairs)
+    head.lru.restore([(int(k), int(k)) for k in range(4096)])
+    labels = rng.choice(4096, size=B, replace=False).astype(np.int64)
+    p = torch.from_numpy(common.unit_rows(rng, B, D)).cuda().requires_grad_(True)
+    g = torch.from_numpy(common.unit_rows(rng, B, D)).cuda()
+    loss = head.run_pass(p, g, labels, labels, True)
+    loss.backward()
+    # dense reference: all labels hit -> rows = qp = 0 -> g written to row 0; ones_idx = all label slots,
+    # so variant 2 reads queue[1] at those slots.
+    W = queue0.clone()
+    lab = torch.from_numpy(labels).cuda()
+    W[0, lab] = g
+    pr = p.detach().clone().requires_grad_(True)
+    w2 = W[0].clone()
+    w2[lab] = W[1, lab]
+    tot = 0
+    for w in (W[0], w2):
+        cos = pr @ w.t()
+        gt = cos.gather(1, lab.view(-1, 1))
+        new = gt * np.cos(0.5) - torch.sqrt(1 - gt * gt) * np.sin(0.5)
+        cos = cos.scatter(1, lab.view(-1, 1), new)
+        tot = tot + torch.nn.functional.cross_entropy(cos * 32.0, lab)
+    tot.backward()
+    np.testing.assert_allclose(float(loss), float(tot), rtol=2e-3)
+    np.testing.assert_allclose(p.grad.cpu().numpy(), pr.grad.cpu().numpy(), rtol=5e-2,
+                               atol=4e-3 * float(pr.grad.abs().max()))

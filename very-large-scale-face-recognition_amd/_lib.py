@@ -60,24 +60,11 @@ def _declare(lib):
 
 
 def _declare_device(lib):
-    vp = c_void_p
-    i32 = c_int32
-    i64 = c_int64
-    f32 = c_float
-    dev = {
-        # 3. pool rows
-        "vlsfr_pool_scatter": (c_int, [vp, i64, i32, vp, vp, vp, i32, vp]),
-        # 4. fused DCP head
-        "vlsfr_head_workspace_bytes": (c_size_t, [i32, i32, i64]),
-        "vlsfr_head_fwd_bwd": (c_int, None),
-    }
-    for name, (res, args) in dev.items():
-        if not hasattr(lib, name):
-            continue
-        fn = getattr(lib, name)
-        fn.restype = res
-        if args is not None:
-            fn.argtypes = args
+    """Device entry points take raw pointers; callers pass explicit ctypes values (see head.py,
+    backbone.py), so only the result types are fixed here."""
+    for name in ("vlsfr_pool_scatter", "vlsfr_head_fwd_bwd"):
+        getattr(lib, name).restype = c_int
+    lib.vlsfr_head_workspace_bytes.restype = c_size_t
 
 
 def lib():

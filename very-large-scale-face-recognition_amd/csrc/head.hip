@@ -1,0 +1,861 @@
+// Fused Dynamic-Class-Pool head for gfx950 (C-ABI sections 3-4 of include/vlsfr.h).
+//
+// Replaces, for one FFC pass, reference ffc.py:182/195-203 (commit) and ffc.py:240-258 (rollback):
+// the pool scatter, both pool contractions F.linear(p, queue[0]) / F.linear(p, weight), the
+// mask blend, add_margin (ffc.py:60-138: AM / Arc / SV margins, cross-entropy, hard-negative
+// top-k) and — because queue is a buffer and only dL/dp is needed — the whole backward of that
+// sub-graph, in ONE sweep over queue[0].
+//
+// Design:
+//   * "special columns" (slots written this pass, ones_idx, label slots: <= 3B of them) are masked
+//     out of the sweep and handled exactly in fp32 by head_special/head_finish, per variant
+//     (cos_theta1 vs cos_theta2 differ only there).  The rollback pass therefore never
+//     mutates the pool at all; the commit pass scatters g afterwards.
+//   * head_sweep is a flash-style pass over the remaining columns: S^T = W_tile · P^T on MFMA
+//     (pool column on the MFMA row, so the accumulator already is the A operand of the second
+//     product), online softmax in base 2 with deferred rescale, O += P~ · W_tile on MFMA with the
+//     W tile read back transposed by ds_read_b64_tr_b16.  O/l is the softmax-weighted class
+//     vector, i.e. dL/dp up to the target term — no second sweep for the backward.
+//   * fp32 pool rows are converted to bf16 on the way into LDS (PRECISE: split into hi + lo bf16
+//     and three MFMAs per product ≈ fp32 products, for the fp32-tolerance parity mode).
+//   * per-lane top-k lists feed the hard-negative term of outlier rows (label == -1).
+#include "hip_common.h"
+
+using namespace vlsfr;
+
+namespace {
+
+constexpr int TQ = 32;        // pool columns per tile
+constexpr int ROWS_WG = 64;   // probe rows per workgroup (4 waves x 16)
+constexpr int KTOP = 10;      // max hard_neg (ffc.py:48)
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr float DEFER_THR = 12.0f;  // deferred-rescale threshold in log2 units
+
+struct SweepArgs {
+  const float* p;        // [B, D]
+  const float* w0;       // queue[0], [Q, D]
+  int64_t Q;
+  int32_t B, D;
+  int32_t chunk_cols;    // multiple of TQ
+  int32_t n_chunks;
+  const int32_t* special_col;
+  int32_t n_special;
+  const int32_t* pool_label;  // [B]; -1 rows take part in top-k
+  float qscale;          // scale * log2(e)
+  const float* sv_thr;   // SV: per-row hard-example threshold (cos units) or nullptr
+  float sv_t;            // SV: mask_svfc (1.2)
+  float* part_m;         // [n_chunks, Bp]
+  float* part_l;         // [n_chunks, Bp]
+  float* part_o;         // [n_chunks, Bp, DP]
+  float* topk_val;       // [n_chunks, Bp, 4, KTOP]
+  int32_t* topk_idx;
+  int32_t Bp;
+};
+
+template <int DP>
+__device__ __forceinline__ int swz_off(int row, int chunk16) {
+  // LDS image of a W tile: bf16 rows padded by 32 B.  With that stride both the ds_read_b128 row
+  // reads of the first product (16 rows x 4 chunks per wave-instruction) and the
+  // ds_read_b64_tr_b16 block reads of the second one (8 rows x 32 B per half-wave) are
+  // bank-conflict free, and every per-k-step address is lane_base + immediate.
+  return row * (DP * 2 + 32) + (chunk16 << 4);
+}
+
+template <int DP, bool PRECISE, bool TOPK, bool SV>
+__global__ __launch_bounds__(256, 1) void head_sweep_kernel(SweepArgs a) {
+  constexpr int TILE_B = TQ * (DP * 2 + 32);   // bytes per padded bf16 tile
+  constexpr int KS = DP / 32;                  // k-steps of the first product
+  constexpr int NB = DP / 16;                  // 16-column blocks of the second product
+  constexpr int GROUPS = TQ * DP / 8;          // 8-float groups per tile
+  constexpr int GPT = (GROUPS + 255) / 256;    // groups per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* tile_hi = smem;
+  char* tile_lo = smem + TILE_B;               // PRECISE only
+  uint32_t* bits = (uint32_t*)(smem + (PRECISE ? 2 : 1) * TILE_B);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int r16 = lane & 15;
+  const int h = lane >> 4;
+  const int chunk = blockIdx.x;
+  const int64_t c0 = (int64_t)chunk * a.chunk_cols;
+  const int64_t c1 = (c0 + a.chunk_cols < a.Q) ? c0 + a.chunk_cols : a.Q;
+  const int ntiles = (int)((c1 - c0 + TQ - 1) / TQ);
+  const int row_base = blockIdx.y * ROWS_WG + wave * 16;
+  const bool wave_active = row_base < a.B;     // wave-uniform
+
+  // ---- special-column bitmap of this chunk
+  const int nwords = a.chunk_cols / 32;
+  for (int i = tid; i < nwords; i += 256) bits[i] = 0u;
+  __syncthreads();
+  for (int i = tid; i < a.n_special; i += 256) {
+    int64_t c = a.special_col[i];
+    if (c >= c0 && c < c1) atomicOr(&bits[(c - c0) >> 5], 1u << ((c - c0) & 31));
+  }
+
+  // ---- P fragments (B operand of S^T = W · P^T): lane holds P[row r16][32ks + 8h + j]
+  bf16x8 pf_hi[KS];
+  bf16x8 pf_lo[PRECISE ? KS : 1];
+  {
+    const int prow = row_base + r16;
+    const bool ok = wave_active && prow < a.B;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int d = ks * 32 + h * 8 + j;
+        float v = (ok && d < a.D) ? a.p[(size_t)prow * a.D + d] : 0.f;
+        __bf16 hi = (__bf16)v;
+        pf_hi[ks][j] = hi;
+        if constexpr (PRECISE) pf_lo[ks][j] = (__bf16)(v - (float)hi);
+      }
+    }
+  }
+  float sv_thr = 0.f;
+  bool is_out = false;
+  {
+    const int prow = row_base + r16;
+    if (wave_active && prow < a.B) {
+      if (SV) sv_thr = a.sv_thr[prow];
+      if (TOPK) is_out = a.pool_label[prow] < 0;
+    }
+  }
+
+  // ---- accumulators
+  f32x4 oacc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) oacc[nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_ref = NEG_BIG;   // reference exponent of row r16 (log2 units), identical in the 4 h-lanes
+  float l_part = 0.f;      // this lane's share of sum 2^(s - m_ref)
+  float tk_v[KTOP];
+  int tk_i[KTOP];
+#pragma unroll
+  for (int k = 0; k < KTOP; ++k) {
+    tk_v[k] = NEG_BIG;
+    tk_i[k] = -1;
+  }
+
+  // ---- tile staging registers: thread loads GPT groups of 8 consecutive floats
+  f32x4 st[GPT][2];
+  auto issue_loads = [&](int t) {
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+      const int e = tid + 256 * u;
+      const int row = e / (DP / 8);
+      const int c8 = e % (DP / 8);
+      const int64_t cg = c0 + (int64_t)t * TQ + row;
+      const bool ok = (e < GROUPS) && (cg < c1) && (c8 * 8 < a.D);
+      if (ok) {
+        const f32x4* src = (const f32x4*)(a.w0 + (size_t)cg * a.D + c8 * 8);
+        st[u][0] = src[0];
+        st[u][1] = src[1];
+      } else {
+        st[u][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        st[u][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto write_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < GPT; ++u) {
+      const int e = tid + 256 * u;
+      if (e < GROUPS) {
+        const int row = e / (DP / 8);
+        const int c8 = e % (DP / 8);
+        const float v[8] = {st[u][0][0], st[u][0][1], st[u][0][2], st[u][0][3],
+                            st[u][1][0], st[u][1][1], st[u][1][2], st[u][1][3]};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          hi[j] = (__bf16)v[j];
+          if (PRECISE) lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        }
+        const int off = swz_off<DP>(row, c8);
+        *(bf16x8*)(tile_hi + off) = hi;
+        if (PRECISE) *(bf16x8*)(tile_lo + off) = lo;
+      }
+    }
+  };
+
+  if (ntiles > 0) issue_loads(0);
+  for (int t = 0; t < ntiles; ++t) {
+    write_tile();
+    __syncthreads();
+    if (t + 1 < ntiles) issue_loads(t + 1);
+    if (wave_active) {
+      // ================= first product: S^T[j][i] for j in 2 blocks of 16 pool columns
+      f32x4 sacc[2];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int row = jb * 16 + r16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int off = swz_off<DP>(row, ks * 4 + h);
+          bf16x8 wa = *(const bf16x8*)(tile_hi + off);
+          acc = mfma16(wa, pf_hi[ks], acc);
+          if constexpr (PRECISE) {
+            bf16x8 wl = *(const bf16x8*)(tile_lo + off);
+            acc = mfma16(wa, pf_lo[ks], acc);
+            acc = mfma16(wl, pf_hi[ks], acc);
+          }
+          if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the ds_read run-ahead (VGPR pressure)
+        }
+        sacc[jb] = acc;
+      }
+      // lane (r16, h) now holds cos(p_row r16, pool column tile + 16jb + 4h + e), e = 0..3
+      float s[8];
+      float av[8];      // SV derivative factor
+      bool valid[8];
+      float tmax = NEG_BIG;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int jloc = t * TQ + jb * 16 + 4 * h;             // column offset inside the chunk
+        const uint32_t word = bits[jloc >> 5];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int q = jb * 4 + e;
+          const int64_t cg = c0 + jloc + e;
+          const bool ok = (cg < c1) && !((word >> ((jloc + e) & 31)) & 1u);
+          float c = sacc[jb][e];
+          if (TOPK) {
+            if (ok && is_out && c > tk_v[KTOP - 1]) {           // rare after warm-up
+              float cv = c;
+              int ci = (int)cg;
+#pragma unroll
+              for (int k = 0; k < KTOP; ++k) {
+                const bool gt = cv > tk_v[k];
+                const float tv = tk_v[k];
+                const int ti = tk_i[k];
+                tk_v[k] = gt ? cv : tv;
+                tk_i[k] = gt ? ci : ti;
+                cv = gt ? tv : cv;
+                ci = gt ? ti : ci;
+              }
+            }
+          }
+          float fac = 1.f;
+          if (SV) {
+            if (c > sv_thr) {                                   // ffc.py:122-125
+              c = a.sv_t * c + a.sv_t - 1.f;
+              fac = a.sv_t;
+            }
+          }
+          av[q] = fac;
+          valid[q] = ok;
+          s[q] = ok ? c * a.qscale : NEG_BIG;
+          tmax = fmaxf(tmax, s[q]);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      // deferred rescale: move the reference exponent only when the row maximum outgrows it
+      const bool grow = tmax > m_ref + DEFER_THR;
+      if (__any(grow)) {
+        const float m_new = grow ? tmax : m_ref;
+        const float alpha = grow ? exp2f(m_ref - m_new) : 1.f;
+        m_ref = m_new;
+        l_part *= alpha;
+        float al[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) al[e] = __shfl(alpha, 4 * h + e, 64);   // O rows are 4h + e
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) oacc[nb][e] *= al[e];
+        }
+      }
+      bf16x8 pa_hi, pa_lo;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float pe = valid[q] ? exp2f(s[q] - m_ref) : 0.f;
+        l_part += pe;
+        const float pw = SV ? pe * av[q] : pe;
+        const __bf16 hi = (__bf16)pw;
+        pa_hi[q] = hi;
+        if constexpr (PRECISE) pa_lo[q] = (__bf16)(pw - (float)hi);
+      }
+      // ================= second product: O[i][d] += sum_j P~[i][j] W[j][d]
+      // k index of the MFMA: element q of lane group h  <->  tile row 16 (q>>2) + 4h + (q&3),
+      // which is exactly how pa_* is laid out; B comes from two transposed 4x16 block reads.
+      const int trow0 = 4 * h + (r16 >> 2);            // block row supplied by this lane (first block)
+      const int tsub = (r16 & 3);                      // 4-column group inside the 16-column block
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int ch = nb * 2 + (tsub >> 1);
+        const int o0 = swz_off<DP>(trow0, ch) + 8 * (tsub & 1);
+        const int o1 = swz_off<DP>(trow0 + 16, ch) + 8 * (tsub & 1);
+        short4v b0 = lds_read_tr16(tile_hi + o0);
+        short4v b1 = lds_read_tr16(tile_hi + o1);
+        short __attribute__((ext_vector_type(8))) bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        bf16x8 wb = __builtin_bit_cast(bf16x8, bs);
+        oacc[nb] = mfma16(pa_hi, wb, oacc[nb]);
+        if constexpr (PRECISE) {
+          short4v l0 = lds_read_tr16(tile_lo + o0);
+          short4v l1 = lds_read_tr16(tile_lo + o1);
+          short __attribute__((ext_vector_type(8))) ls = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+          bf16x8 wl = __builtin_bit_cast(bf16x8, ls);
+          oacc[nb] = mfma16(pa_hi, wl, oacc[nb]);
+          oacc[nb] = mfma16(pa_lo, wb, oacc[nb]);
+        }
+        if ((nb & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write partials
+  if (wave_active) {
+    float l_row = l_part;
+    l_row += __shfl_xor(l_row, 16, 64);
+    l_row += __shfl_xor(l_row, 32, 64);
+    const int prow = row_base + r16;
+    const size_t pr = (size_t)chunk * a.Bp + prow;
+    if (h == 0) {
+      a.part_m[pr] = m_ref;
+      a.part_l[pr] = l_row;
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const size_t orow = (size_t)chunk * a.Bp + row_base + 4 * h + e;
+        a.part_o[orow * DP + nb * 16 + r16] = oacc[nb][e];
+      }
+    }
+    if (TOPK) {
+      const size_t base = (pr * 4 + h) * KTOP;
+#pragma unroll
+      for (int k = 0; k < KTOP; ++k) {
+        a.topk_val[base + k] = tk_v[k];
+        a.topk_idx[base + k] = tk_i[k];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head_special: exact fp32 cosines of every probe row against the <= 3B special columns, for both
+// variants (cos_theta1: queue[0] after this pass's writes; cos_theta2: mask-blended weight).
+// ------------------------------------------------------------------------------------------------
+struct SpecialArgs {
+  const float* p;
+  const float* g;
+  const float* queue;   // [2, Q, D]
+  int64_t Q;
+  int32_t B, D, n_special;
+  const int32_t* special_col;
+  const int32_t* src1;
+  const int32_t* src2;
+  float* cos1;          // [B, n_special]
+  float* cos2;
+};
+
+__device__ __forceinline__ const float* special_vec(const float* g, const float* queue, int64_t Q, int D, int col,
+                                                    int src) {
+  if (src >= 0) return g + (size_t)src * D;
+  if (src == -1) return queue + (size_t)col * D;
+  return queue + ((size_t)Q + col) * D;
+}
+
+__global__ __launch_bounds__(256) void head_special_kernel(SpecialArgs a) {
+  const int s = blockIdx.x;
+  const int col = a.special_col[s];
+  const int s1 = a.src1[s], s2 = a.src2[s];
+  const float* v1 = special_vec(a.g, a.queue, a.Q, a.D, col, s1);
+  const float* v2 = special_vec(a.g, a.queue, a.Q, a.D, col, s2);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = wave; i < a.B; i += 4) {
+    float d1 = 0.f, d2 = 0.f;
+    for (int d = lane; d < a.D; d += 64) {
+      const float pv = a.p[(size_t)i * a.D + d];
+      d1 += pv * v1[d];
+      d2 += pv * v2[d];
+    }
+    d1 = wave_sum(d1);
+    d2 = (s1 == s2) ? d1 : wave_sum(d2);
+    if (lane == 0) {
+      a.cos1[(size_t)i * a.n_special + s] = d1;
+      a.cos2[(size_t)i * a.n_special + s] = d2;
+    }
+  }
+}
+
+// SV hard-example thresholds gt - margin per row and variant (ffc.py:121-122)
+__global__ void head_sv_thr_kernel(const int32_t* pool_label, const int32_t* special_col, int n_special, int B,
+                                   const float* cos1, const float* cos2, float margin, float* thr1, float* thr2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int t = pool_label[i];
+  float g1 = 3.0e38f, g2 = 3.0e38f;   // outlier rows: no column is "hard"
+  if (t >= 0) {
+    for (int s = 0; s < n_special; ++s)
+      if (special_col[s] == t) {
+        g1 = cos1[(size_t)i * n_special + s] - margin;
+        g2 = cos2[(size_t)i * n_special + s] - margin;
+        break;
+      }
+  }
+  thr1[i] = g1;
+  thr2[i] = g2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// head_finish: one workgroup per probe row.  Merges the sweep partials with the special columns,
+// applies the margin on the target column, and emits the row's loss terms and dL/dp.
+// ------------------------------------------------------------------------------------------------
+struct FinishArgs {
+  const float* g;
+  const float* queue;
+  int64_t Q;
+  int32_t B, D, DP, Bp, n_chunks, n_special;
+  const int32_t* pool_label;
+  const int32_t* special_col;
+  const int32_t* src1;
+  const int32_t* src2;
+  const float* cos1;
+  const float* cos2;
+  const float* part_m[2];   // per variant (identical pointers unless SV)
+  const float* part_l[2];
+  const float* part_o[2];
+  const float* topk_val;
+  const int32_t* topk_idx;
+  int32_t loss_type;        // 0 AM, 1 Arc, 2 SV
+  float scale, margin, sv_t;
+  int32_t hard_neg, n_pos, n_out;
+  float* row_loss;          // [B, 2]
+  float* dP;                // [B, D]
+};
+
+__global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int D = a.D;
+  float* dp = (float*)smem;                     // [D] accumulated gradient of this row
+  float* red = dp + ((D + 3) & ~3);             // [16] scratch
+  float* wts = red + 16;                        // [max(n_chunks, n_special)] per-chunk / per-special weights
+  const int label = a.pool_label[i];
+  const float qs = a.scale * LOG2E;
+  for (int d = tid; d < D; d += 256) dp[d] = 0.f;
+  __shared__ float sh_val[4];
+  __shared__ int sh_idx[4];
+  __syncthreads();
+
+  auto block_max = [&](float v) -> float {
+    v = wave_max(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+  };
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+  };
+
+  if (label >= 0) {
+    // ---------------------------------------------------------------- positive row: margin + CE
+    if (tid == 0) sh_idx[0] = -1;
+    __syncthreads();
+    for (int s = tid; s < a.n_special; s += 256)
+      if (a.special_col[s] == label) sh_idx[0] = s;
+    __syncthreads();
+    const int st = sh_idx[0];   // the label slot is always a special column (vlsfr_dcp_assign)
+    __syncthreads();
+    const float inv_pos = 1.f / (float)a.n_pos;
+    for (int v = 0; v < 2; ++v) {
+      const float* cs = (v == 0 ? a.cos1 : a.cos2) + (size_t)i * a.n_special;
+      const int32_t* src = (v == 0 ? a.src1 : a.src2);
+      const float gt = st >= 0 ? cs[st] : 0.f;
+      float tm, dtm;   // modified target cosine and d(tm)/d(gt)
+      if (a.loss_type == 0) {
+        tm = gt - a.margin;
+        dtm = 1.f;
+      } else if (a.loss_type == 1) {
+        const float sn = sqrtf(1.f - gt * gt);            // no clamp (ffc.py:101)
+        tm = gt * cosf(a.margin) - sn * sinf(a.margin);
+        dtm = cosf(a.margin) + gt / sn * sinf(a.margin);
+      } else {
+        tm = (gt > a.margin) ? gt - a.margin : gt;         // ffc.py:123
+        dtm = 1.f;
+      }
+      const float thr = gt - a.margin;                     // SV hard-example threshold
+      // --- global exponent
+      float mx = NEG_BIG;
+      for (int c = tid; c < a.n_chunks; c += 256) mx = fmaxf(mx, a.part_m[v][(size_t)c * a.Bp + i]);
+      for (int s = tid; s < a.n_special; s += 256) {
+        float c = cs[s];
+        if (s == st) c = tm;
+        else if (a.loss_type == 2 && c > thr) c = a.sv_t * c + a.sv_t - 1.f;
+        mx = fmaxf(mx, c * qs);
+      }
+      const float M = block_max(mx);
+      // --- denominator and per-chunk weights
+      float lsum = 0.f;
+      for (int c = tid; c < a.n_chunks; c += 256) {
+        const float w = exp2f(a.part_m[v][(size_t)c * a.Bp + i] - M);
+        wts[c] = w;
+        lsum += w * a.part_l[v][(size_t)c * a.Bp + i];
+      }
+      __syncthreads();
+      float zt = 0.f;
+      float sp_l = 0.f;
+      for (int s = tid; s < a.n_special; s += 256) {
+        float c = cs[s];
+        if (s == st) c = tm;
+        else if (a.loss_type == 2 && c > thr) c = a.sv_t * c + a.sv_t - 1.f;
+        sp_l += exp2f(c * qs - M);
+      }
+      const float L = block_sum(lsum + sp_l);
+      zt = tm * a.scale;
+      if (tid == 0) a.row_loss[(size_t)i * 2 + v] = (LN2 * (M + log2f(L)) - zt) * inv_pos;
+      // --- gradient: swept part
+      const float gscale = a.scale * inv_pos / L;
+      for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int c = 0; c < a.n_chunks; ++c) acc += wts[c] * a.part_o[v][((size_t)c * a.Bp + i) * a.DP + d];
+        dp[d] += gscale * acc;
+      }
+      __syncthreads();
+      // --- gradient: special columns (softmax weight times d logit / d cos) and the -1 of the target
+      for (int s = tid; s < a.n_special; s += 256) {
+        float c = cs[s];
+        float fac = 1.f;
+        if (s == st) {
+          c = tm;
+          fac = dtm;
+        } else if (a.loss_type == 2 && c > thr) {
+          c = a.sv_t * c + a.sv_t - 1.f;
+          fac = a.sv_t;
+        }
+        float w = exp2f(c * qs - M) * gscale * fac;
+        if (s == st) w -= a.scale * inv_pos * dtm;
+        wts[s] = w;
+      }
+      __syncthreads();
+      for (int s = 0; s < a.n_special; ++s) {
+        const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[s], src[s]);
+        const float w = wts[s];
+        for (int d = tid; d < D; d += 256) dp[d] += w * vec[d];
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---------------------------------------------------------------- outlier row: hard negatives
+    const float inv = 1.f / ((float)a.n_out * (float)a.hard_neg);
+    const size_t ncand_sweep = (size_t)a.n_chunks * 4 * KTOP;
+    for (int v = 0; v < 2; ++v) {
+      const float* cs = (v == 0 ? a.cos1 : a.cos2) + (size_t)i * a.n_special;
+      const int32_t* src = (v == 0 ? a.src1 : a.src2);
+      float loss = 0.f;
+      float last_v = 3.0e38f;
+      long long last_k = -1;   // candidates are consumed in (value desc, key asc) order
+      for (int k = 0; k < a.hard_neg; ++k) {
+        float bv = NEG_BIG;
+        long long bk = 0x7fffffffffffffffLL;
+        auto consider = [&](float cv, long long key) {
+          if (cv <= NEG_BIG) return;
+          const bool after = (cv < last_v) || (cv == last_v && key > last_k);
+          if (!after) return;
+          if (cv > bv || (cv == bv && key < bk)) {
+            bv = cv;
+            bk = key;
+          }
+        };
+        for (size_t c = tid; c < ncand_sweep; c += 256) {
+          const size_t chunk = c / (4 * KTOP), rest = c % (4 * KTOP);
+          const size_t off = ((chunk * a.Bp + i) * 4) * KTOP + rest;
+          consider(a.topk_val[off], (long long)a.topk_idx[off]);
+        }
+        for (int s = tid; s < a.n_special; s += 256) consider(cs[s], (long long)a.Q + s);
+        // block arg-max on (value, -key)
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const long long ok = __shfl_xor(bk, o, 64);
+          if (ov > bv || (ov == bv && ok < bk)) {
+            bv = ov;
+            bk = ok;
+          }
+        }
+        __shared__ float wv[4];
+        __shared__ long long wk[4];
+        if (lane == 0) {
+          wv[wave] = bv;
+          wk[wave] = bk;
+        }
+        __syncthreads();
+        bv = wv[0];
+        bk = wk[0];
+        for (int w = 1; w < 4; ++w)
+          if (wv[w] > bv || (wv[w] == bv && wk[w] < bk)) {
+            bv = wv[w];
+            bk = wk[w];
+          }
+        __syncthreads();
+        if (bv <= NEG_BIG) break;       // fewer than hard_neg candidates (tiny pools)
+        last_v = bv;
+        last_k = bk;
+        if (bv >= 0.f) {                 // clip(min=0) (ffc.py:89): negative cosines contribute nothing
+          loss += bv;
+          const float* vec = (bk >= a.Q) ? special_vec(a.g, a.queue, a.Q, D, a.special_col[bk - a.Q], src[bk - a.Q])
+                                         : a.queue + (size_t)bk * D;
+          for (int d = tid; d < D; d += 256) dp[d] += inv * vec[d];
+        }
+      }
+      if (tid == 0) a.row_loss[(size_t)i * 2 + v] = loss * inv;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) a.dP[(size_t)i * D + d] = dp[d];
+}
+
+__global__ void head_loss_reduce_kernel(const float* row_loss, int n, float* out) {
+  // fixed-order sum: the scalar loss is bitwise reproducible run to run
+  __shared__ float sh[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += row_loss[i];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// queue[rows[i], cols[i]] = g[i]; duplicates resolved "highest batch index wins"
+__global__ __launch_bounds__(256) void pool_scatter_kernel(float* queue, int64_t Q, int D, const float* g,
+                                                           const int32_t* rows, const int32_t* cols, int n) {
+  const int i = blockIdx.x;
+  const int r = rows[i], c = cols[i];
+  __shared__ int dead;
+  if (threadIdx.x == 0) dead = 0;
+  __syncthreads();
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256)
+    if (rows[j] == r && cols[j] == c) dead = 1;
+  __syncthreads();
+  if (dead) return;
+  float* dst = queue + ((size_t)r * Q + c) * D;
+  const float* src = g + (size_t)i * D;
+  for (int d = threadIdx.x; d < D; d += 256) dst[d] = src[d];
+}
+
+int round_dp(int D) {
+  int dp = 32;
+  while (dp < D) dp <<= 1;
+  return dp;
+}
+
+struct Plan {
+  int DP, Bp, n_chunks, chunk_cols, n_rowblk;
+  size_t off_m, off_l, off_o, off_tv, off_ti, off_cos1, off_cos2, off_thr, off_rowloss, total;
+  int n_sets;
+};
+
+int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
+  if (!c || c->B <= 0 || c->D <= 0 || c->Q <= 0) return fail(VLSFR_EINVAL, "head: B, D, Q must be positive");
+  if (c->D % 16 != 0 || c->D > 512) return fail(VLSFR_EINVAL, "head: feat_dim must be a multiple of 16 and <= 512 (got %d)", c->D);
+  if (c->Q > 0x7fffffffLL) return fail(VLSFR_EINVAL, "head: a pool shard holds at most 2^31-1 slots");
+  if (c->loss_type < 0 || c->loss_type > 2) return fail(VLSFR_EINVAL, "head: loss_type must be 0 (AM), 1 (Arc) or 2 (SV)");
+  if (c->hard_neg < 1 || c->hard_neg > KTOP) return fail(VLSFR_EINVAL, "head: hard_neg must be in [1, 10]");
+  pl->DP = round_dp(c->D);
+  pl->n_rowblk = (c->B + ROWS_WG - 1) / ROWS_WG;
+  pl->Bp = pl->n_rowblk * ROWS_WG;
+  int64_t tiles = (c->Q + TQ - 1) / TQ;
+  int nch = c->n_chunks > 0 ? c->n_chunks : 256;
+  if (nch > tiles) nch = (int)tiles;
+  int64_t per = (tiles + nch - 1) / nch;
+  if (per > 1024) {   // bound the special-column bitmap (4 KiB of LDS)
+    per = 1024;
+    nch = (int)((tiles + per - 1) / per);
+  }
+  pl->chunk_cols = (int)per * TQ;
+  pl->n_chunks = (int)((c->Q + pl->chunk_cols - 1) / pl->chunk_cols);
+  pl->n_sets = (c->loss_type == 2) ? 2 : 1;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t rowsz = (size_t)pl->n_chunks * pl->Bp;
+  pl->off_m = take(rowsz * 4 * pl->n_sets);
+  pl->off_l = take(rowsz * 4 * pl->n_sets);
+  pl->off_o = take(rowsz * pl->DP * 4 * pl->n_sets);
+  pl->off_tv = take(rowsz * 4 * KTOP * 4);
+  pl->off_ti = take(rowsz * 4 * KTOP * 4);
+  pl->off_cos1 = take((size_t)c->B * 3 * c->B * 4);
+  pl->off_cos2 = take((size_t)c->B * 3 * c->B * 4);
+  pl->off_thr = take((size_t)pl->Bp * 4 * 2);
+  pl->off_rowloss = take((size_t)c->B * 2 * 4);
+  pl->total = off;
+  return VLSFR_OK;
+}
+
+template <int DP, bool PRECISE>
+int launch_sweep(const SweepArgs& a, bool topk, bool sv, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)(PRECISE ? 2 : 1) * TQ * (DP * 2 + 32) + (size_t)a.chunk_cols / 8 + 16;
+#define VLSFR_SWEEP(T, S)                                                                              \
+  do {                                                                                                \
+    auto kern = head_sweep_kernel<DP, PRECISE, T, S>;                                                 \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return hip_fail(e, "head_sweep: hipFuncSetAttribute");                       \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);                                            \
+  } while (0)
+  if (topk && sv) VLSFR_SWEEP(true, true);
+  else if (topk) VLSFR_SWEEP(true, false);
+  else if (sv) VLSFR_SWEEP(false, true);
+  else VLSFR_SWEEP(false, false);
+#undef VLSFR_SWEEP
+  VLSFR_HIP_CHECK_LAUNCH("head_sweep launch");
+  return VLSFR_OK;
+}
+
+template <bool PRECISE>
+int dispatch_sweep(int DP, const SweepArgs& a, bool topk, bool sv, dim3 grid, hipStream_t st) {
+  switch (DP) {
+    case 32: return launch_sweep<32, PRECISE>(a, topk, sv, grid, st);
+    case 64: return launch_sweep<64, PRECISE>(a, topk, sv, grid, st);
+    case 128: return launch_sweep<128, PRECISE>(a, topk, sv, grid, st);
+    case 256: return launch_sweep<256, PRECISE>(a, topk, sv, grid, st);
+    case 512: return launch_sweep<512, PRECISE>(a, topk, sv, grid, st);
+  }
+  return fail(VLSFR_EINVAL, "head_sweep: unsupported padded feat_dim %d", DP);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g, const int32_t* rows, const int32_t* cols,
+                       int32_t n, void* stream) {
+  if (!queue || !g || !rows || !cols || Q <= 0 || D <= 0 || n < 0)
+    return fail(VLSFR_EINVAL, "vlsfr_pool_scatter: bad argument");
+  if (n == 0) return VLSFR_OK;
+  hipLaunchKernelGGL(pool_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, queue, Q, D, g, rows, cols, n);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_pool_scatter launch");
+  return VLSFR_OK;
+}
+
+size_t vlsfr_head_workspace_bytes(const vlsfr_head_cfg* cfg) {
+  Plan pl;
+  if (make_plan(cfg, &pl) != VLSFR_OK) return 0;
+  return pl.total;
+}
+
+int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                       const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                       const int32_t* src2, int32_t n_special, int32_t n_pos, float* loss_out, float* dP,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  Plan pl;
+  int rc = make_plan(cfg, &pl);
+  if (rc != VLSFR_OK) return rc;
+  if (!p || !g || !queue || !pool_label || !loss_out || !dP || !workspace)
+    return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: null argument");
+  if (n_special < 0 || n_special > 3 * cfg->B || (n_special > 0 && (!special_col || !src1 || !src2)))
+    return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: bad special-column table");
+  if (n_pos < 0 || n_pos > cfg->B) return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: n_pos out of range");
+  if (workspace_bytes < pl.total)
+    return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int B = cfg->B, D = cfg->D;
+  const int n_out = B - n_pos;
+  float* cos1 = (float*)(ws + pl.off_cos1);
+  float* cos2 = (float*)(ws + pl.off_cos2);
+  float* thr = (float*)(ws + pl.off_thr);
+  float* row_loss = (float*)(ws + pl.off_rowloss);
+  const size_t rowsz = (size_t)pl.n_chunks * pl.Bp;
+
+  if (n_special > 0) {
+    SpecialArgs sa{p, g, queue, cfg->Q, B, D, n_special, special_col, src1, src2, cos1, cos2};
+    hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
+    VLSFR_HIP_CHECK_LAUNCH("head_special launch");
+  }
+  const bool sv = cfg->loss_type == 2;
+  if (sv) {
+    hipLaunchKernelGGL(head_sv_thr_kernel, dim3((B + 255) / 256), dim3(256), 0, st, pool_label, special_col,
+                       n_special, B, cos1, cos2, cfg->margin, thr, thr + pl.Bp);
+    VLSFR_HIP_CHECK_LAUNCH("head_sv_thr launch");
+  }
+  SweepArgs a;
+  a.p = p;
+  a.w0 = queue;
+  a.Q = cfg->Q;
+  a.B = B;
+  a.D = D;
+  a.chunk_cols = pl.chunk_cols;
+  a.n_chunks = pl.n_chunks;
+  a.special_col = special_col;
+  a.n_special = n_special;
+  a.pool_label = pool_label;
+  a.qscale = cfg->scale * LOG2E;
+  a.sv_t = 1.2f;   // ffc.py:47 mask_svfc
+  a.topk_val = (float*)(ws + pl.off_tv);
+  a.topk_idx = (int32_t*)(ws + pl.off_ti);
+  a.Bp = pl.Bp;
+  const dim3 grid(pl.n_chunks, pl.n_rowblk);
+  for (int set = 0; set < pl.n_sets; ++set) {
+    a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
+    a.part_l = (float*)(ws + pl.off_l) + set * rowsz;
+    a.part_o = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
+    a.sv_thr = sv ? thr + set * pl.Bp : nullptr;
+    const bool topk = (n_out > 0) && set == 0;   // top-k uses raw cosines: variant independent
+    rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st)
+                      : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
+    if (rc != VLSFR_OK) return rc;
+  }
+  FinishArgs f;
+  f.g = g;
+  f.queue = queue;
+  f.Q = cfg->Q;
+  f.B = B;
+  f.D = D;
+  f.DP = pl.DP;
+  f.Bp = pl.Bp;
+  f.n_chunks = pl.n_chunks;
+  f.n_special = n_special;
+  f.pool_label = pool_label;
+  f.special_col = special_col;
+  f.src1 = src1;
+  f.src2 = src2;
+  f.cos1 = cos1;
+  f.cos2 = cos2;
+  for (int v = 0; v < 2; ++v) {
+    const int set = (pl.n_sets == 2) ? v : 0;
+    f.part_m[v] = (float*)(ws + pl.off_m) + set * rowsz;
+    f.part_l[v] = (float*)(ws + pl.off_l) + set * rowsz;
+    f.part_o[v] = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
+  }
+  f.topk_val = (float*)(ws + pl.off_tv);
+  f.topk_idx = (int32_t*)(ws + pl.off_ti);
+  f.loss_type = cfg->loss_type;
+  f.scale = cfg->scale;
+  f.margin = cfg->margin;
+  f.sv_t = 1.2f;
+  f.hard_neg = cfg->hard_neg;
+  f.n_pos = n_pos;
+  f.n_out = n_out;
+  f.row_loss = row_loss;
+  f.dP = dP;
+  const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
+  const size_t lds = ((size_t)((D + 3) & ~3) + 16 + nw) * 4;
+  hipLaunchKernelGGL(head_finish_kernel, dim3(B), dim3(256), lds, st, f);
+  VLSFR_HIP_CHECK_LAUNCH("head_finish launch");
+  hipLaunchKernelGGL(head_loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, 2 * B, loss_out);
+  VLSFR_HIP_CHECK_LAUNCH("head_loss_reduce launch");
+  return VLSFR_OK;
+}
+
+}  // extern "C"

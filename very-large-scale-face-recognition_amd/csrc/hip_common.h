@@ -1,0 +1,53 @@
+// Device-side helpers shared by the gfx950 kernels (wave = 64 lanes, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common_host.h"
+
+namespace vlsfr {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+#define VLSFR_LDS __attribute__((address_space(3)))
+
+// D(16x16 f32) += A(16x32 bf16) * B(32x16 bf16).  Lane l = 16*h + r holds
+//   A[row r][k = 8h + j], B[k = 8h + j][col r]  (j = 0..7)   and   D[row 4h + e][col r] (e = 0..3).
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements is delivered
+// column-major — lane i of the group receives column i, rows 0..3.  Lane 4q + p of the group
+// supplies the LDS address of row q, columns 4p..4p+3 (8-byte aligned).
+__device__ __forceinline__ short4v lds_read_tr16(void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLSFR_LDS short4v*)lds_addr);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int hip_fail(hipError_t e, const char* what) {
+  return fail(VLSFR_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define VLSFR_HIP_CHECK_LAUNCH(what)                              \
+  do {                                                            \
+    hipError_t e__ = hipGetLastError();                           \
+    if (e__ != hipSuccess) return vlsfr::hip_fail(e__, what);     \
+  } while (0)
+
+}  // namespace vlsfr
