@@ -155,6 +155,65 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
 int vlsfr_probe_mfma_tr(const float* A, const float* B, float* C, int32_t row_stride_bytes, void* stream);
 int vlsfr_probe_mfma_nat(const float* A, const float* Bt, float* C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 5. Convolutions on MFMA (device).  Replaces nn.Conv2d forward / input-gradient /
+ *    weight-gradient (model/resnet_arcface.py:5-23,36,39,74,120) and nn.Linear (:95, as a 1x1
+ *    convolution on a 1x1 map).  Activations NHWC bf16; w bf16 [Cout][R][S][Cin]; wT bf16
+ *    [Cin][R][S][Cout]; dw fp32 [Cout][R][S][Cin] (= memory of a channels_last OIHW tensor),
+ *    ACCUMULATED atomically (zero it for a fresh gradient).
+ *    Covered: 3x3 pad 1 and 1x1 pad 0, stride 1 or 2, Cin % 32 == 0, Cout % 8 == 0.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_conv_desc {
+  int32_t N, H, W;      /* input batch and spatial size */
+  int32_t Cin, Cout;
+  int32_t R, S, stride, pad;
+} vlsfr_conv_desc;
+
+/* y: bf16 [N,Ho,Wo,Cout], or fp32 when out_f32 (required for splitk > 1: accumulated atomically) */
+int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk,
+                     int32_t out_f32, void* stream);
+int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream);
+/* splitk <= 0: library choice */
+int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 6. Normalisation / activation / layout kernels (device).  Replaces nn.BatchNorm2d in training
+ *    mode (resnet_arcface.py:35,37,40,75,93), nn.PReLU (:38,76), the residual add (:54), the
+ *    BatchNorm1d + F.normalize embedding tail (:96-98,151) and the layout/precision conversions.
+ *    x, y, dy, dx, residual: bf16 [M, C] (NHWC rows), C % 8 == 0; statistics fp32.
+ * ---------------------------------------------------------------------------------------- */
+/* sums fp32 [2, C] (sum, sum of squares), pre-zeroed, accumulated atomically */
+int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream);
+/* y = prelu(bn(x)) + residual; slope / residual / running_* may be NULL; out_nchw writes y in the
+ * [n][c][hw] flatten order of the reference's fc input (HW = rows per image) */
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums,
+                   const float* gamma, const float* beta, const float* slope, const void* residual,
+                   float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                   float eps, float momentum, int32_t out_nchw, void* stream);
+/* dx = d(prelu(bn(x)))/dx applied to dy (+ dx_add); dgamma/dbeta/dslope are accumulated (+=);
+ * red: fp32 [3, C] scratch */
+int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      const float* slope, float* red, const void* dx_add, float* dgamma, float* dbeta,
+                      float* dslope, int32_t dy_nchw, void* stream);
+int vlsfr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+/* e = normalize(bn1d(fc + fc_bias)); all fp32 [B, D] */
+int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float* z, float* xhat, float* invstd,
+                    float* emb, float* inv_norm, int32_t B, int32_t D, float eps, float momentum,
+                    void* stream);
+int vlsfr_embed_bwd(const float* demb, const float* emb, const float* inv_norm, const float* xhat,
+                    const float* invstd, const float* gamma, float* dz, void* dfc_bf16, float* dbeta,
+                    float* dfc_bias, int32_t B, int32_t D, void* stream);
+/* fp32 [rows][taps][C] -> bf16 [rows][Kp] (zero padded to Kp >= taps*C) and optionally the
+ * dgrad operand wT bf16 [C][taps][rows] */
+int vlsfr_cast_weight(const float* w, void* w_bf16, void* wT_bf16, int32_t rows, int32_t taps, int32_t C,
+                      int32_t Kp, void* stream);
+/* fp32 NCHW image [N,3,H,W] -> bf16 im2col rows [N*H*W][32] of the 3x3 pad-1 stem (k=(r*3+s)*3+c) */
+int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, void* stream);
+int vlsfr_unpad_add(const float* src, float* dst, int32_t rows, int32_t Ksrc, int32_t Kdst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

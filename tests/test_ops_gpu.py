@@ -1,0 +1,191 @@
+"""Per-kernel parity of the backbone operators (conv fwd / dgrad / wgrad on MFMA, BN / PReLU / add,
+embedding tail) against plain PyTorch fp32 CPU ops on the same bf16-rounded inputs.
+
+Tolerances: operands are bf16 (exactly representable in the fp32 reference, since the reference is
+fed the rounded values), accumulation fp32, outputs rounded once to bf16 (2^-9 relative) — so
+conv outputs agree to rtol 1e-2 of the tensor scale; fp32 outputs (wgrad, split-K) to 1e-3."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def close(got, want, rel):
+    got, want = got.float().cpu(), want.float()
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got - want).abs().max())
+    assert err <= rel * scale, "max err %.4g vs scale %.4g (rel %.3g > %.3g)" % (err, scale, err / scale, rel)
+
+
+# every distinct iResNet conv shape (SURVEY §8 a-conv) at a small batch, plus ragged pixel counts
+IR_SHAPES = [
+    (32, 64, 1, 1, 0, 20),     # stem after im2col: 1x1 over 32-wide rows
+    (64, 64, 3, 1, 1, 28), (64, 64, 3, 2, 1, 28), (64, 64, 1, 2, 0, 28), (64, 128, 3, 1, 1, 14),
+    (128, 128, 3, 2, 1, 14), (64, 128, 1, 2, 0, 14), (128, 128, 3, 1, 1, 14), (128, 256, 3, 1, 1, 14),
+    (256, 256, 3, 2, 1, 14), (128, 256, 1, 2, 0, 14), (256, 256, 3, 1, 1, 14), (256, 512, 3, 1, 1, 14),
+    (512, 512, 3, 2, 1, 14), (256, 512, 1, 2, 0, 14), (512, 512, 3, 1, 1, 7), (64, 64, 3, 1, 1, 13),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw", IR_SHAPES)
+def test_conv_fwd_dgrad_wgrad(cin, cout, k, stride, pad, hw):
+    from vlsfr_amd import ops
+    torch.manual_seed(cin * 7 + cout + k + stride + hw)
+    N = 3
+    x = bf(torch.randn(N, cin, hw, hw))
+    w = bf(torch.randn(cout, cin, k, k) * 0.1)
+    y_ref = F.conv2d(x, w, None, stride, pad)
+    dy = bf(torch.randn_like(y_ref))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride, pad).backward(dy)
+
+    d = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad)
+    xg = nhwc(x).cuda().to(torch.bfloat16)
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().cuda()            # fp32 [Cout][R][S][Cin]
+    wb, wT = ops.cast_weight(w_krsc, cout, k * k, cin)
+    y = ops.conv2d_fwd(xg, wb, d)
+    close(y.permute(0, 3, 1, 2), bf(y_ref), 1e-2)
+    dyg = nhwc(dy).cuda().to(torch.bfloat16)
+    if cout % 32 == 0:
+        dx = ops.conv2d_dgrad(dyg, wT, d)
+        close(dx.permute(0, 3, 1, 2), xr.grad, 1e-2)
+    dw = ops.conv2d_wgrad(dyg, xg, d)
+    close(dw.permute(0, 3, 1, 2), wr.grad, 2e-3)
+    dw2 = ops.conv2d_wgrad(dyg, xg, d, dw=dw.clone(), splitk=3)     # accumulates into an existing gradient
+    close(dw2.permute(0, 3, 1, 2), 2 * wr.grad, 2e-3)
+
+
+@pytest.mark.parametrize("B,K,D", [(8, 25088, 32), (64, 25088, 512), (5, 512, 128)])
+def test_fc_as_conv(B, K, D):
+    """nn.Linear(25088 -> D) forward (split-K, fp32 atomics), input gradient and weight gradient."""
+    from vlsfr_amd import ops
+    torch.manual_seed(B + D)
+    x = bf(torch.randn(B, K))
+    w = bf(torch.randn(D, K) * 0.02)
+    y_ref = x @ w.t()
+    dy = bf(torch.randn(B, D))
+    d = ops.ConvDesc(B, 1, 1, K, D, 1, 1, 1, 0)
+    xg = x.cuda().to(torch.bfloat16)
+    wb, wT = ops.cast_weight(w.cuda(), D, 1, K)
+    y = ops.conv2d_fwd(xg, wb, d, splitk=16, out_f32=True)
+    close(y.reshape(B, D), y_ref, 1e-3)
+    dyg = dy.cuda().to(torch.bfloat16)
+    if D % 32 == 0:
+        dx = ops.conv2d_dgrad(dyg, wT, d)
+        close(dx.reshape(B, K), dy @ w, 1e-2)
+    dw = ops.conv2d_wgrad(dyg, xg, d)
+    close(dw.reshape(D, K), dy.t() @ x, 2e-3)
+
+
+def test_stem_im2col_matches_conv():
+    from vlsfr_amd import ops
+    torch.manual_seed(0)
+    N, H = 2, 20
+    x = torch.randn(N, 3, H, H)
+    w = bf(torch.randn(64, 3, 3, 3) * 0.1)
+    cols = ops.stem_im2col(x.cuda())                                  # bf16 [N*H*W, 32]
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().cuda()                # [64][3][3][3] = [64][27]
+    wb, _ = ops.cast_weight(w_krsc, 64, 1, 27, Kp=32, transpose=False)
+    d = ops.ConvDesc(N, H, H, 32, 64, 1, 1, 1, 0)
+    y = ops.conv2d_fwd(cols, wb, d)
+    close(y.permute(0, 3, 1, 2), bf(F.conv2d(bf(x), w, None, 1, 1)), 1e-2)
+
+
+@pytest.mark.parametrize("C,HW,N,prelu,res", [(64, 49, 4, True, False), (128, 196, 3, False, True), (512, 49, 5, True, True),
+                                              (24, 30, 2, False, False)])
+def test_bn_prelu_add_fwd_bwd(C, HW, N, prelu, res):
+    from vlsfr_amd import ops
+    torch.manual_seed(C + HW)
+    M = N * HW
+    x = bf(torch.randn(M, C) * 2 + 0.5)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    slope = torch.rand(C) * 0.5 if prelu else None
+    resid = bf(torch.randn(M, C)) if res else None
+    rm, rv = torch.zeros(C), torch.ones(C)
+    # reference (NCHW-free: treat rows as the batch axis of BatchNorm1d-style statistics)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    sr = slope.clone().requires_grad_(True) if prelu else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    if prelu:
+        z = torch.where(z > 0, z, z * sr)
+    out_ref = z + resid if res else z
+    dy = bf(torch.randn(M, C))
+    out_ref.backward(dy)
+
+    xg = x.cuda().to(torch.bfloat16)
+    sums = ops.bn_stats(xg, M, C)
+    rmg, rvg = rm.cuda(), rv.cuda()
+    y, mean, invstd = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), slope.cuda() if prelu else None,
+                                   resid.cuda().to(torch.bfloat16) if res else None, rmg, rvg)
+    close(y.reshape(M, C), bf(out_ref.detach()), 1e-2)
+    close(rmg, rm_ref, 1e-4)
+    close(rvg, rv_ref, 1e-4)
+    dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dslope = torch.zeros(C, device="cuda") if prelu else None
+    dx = ops.bn_backward(dy.cuda().to(torch.bfloat16), xg, M, C, HW, mean, invstd, gamma.cuda(), beta.cuda(),
+                         slope.cuda() if prelu else None, None, dgamma, dbeta, dslope)
+    close(dx.reshape(M, C), xr.grad, 2e-2)
+    close(dgamma, gr.grad, 5e-3)
+    close(dbeta, br.grad, 5e-3)
+    if prelu:
+        close(dslope, sr.grad, 5e-3)
+
+
+def test_bn_nchw_flatten_output_and_gradient():
+    """The last BatchNorm2d writes the flatten order the reference's fc consumes ([n][c][h][w])."""
+    from vlsfr_amd import ops
+    torch.manual_seed(3)
+    N, C, HW = 4, 64, 49
+    M = N * HW
+    x = bf(torch.randn(M, C))
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    xg = x.cuda().to(torch.bfloat16)
+    sums = ops.bn_stats(xg, M, C)
+    y, mean, invstd = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), out_nchw=True)
+    y2, _, _ = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), out_nchw=False)
+    want = y2.reshape(N, HW, C).permute(0, 2, 1).reshape(-1)
+    assert torch.equal(y, want.contiguous())
+    dy = bf(torch.randn(N, C, HW))
+    dg = [torch.zeros(C, device="cuda") for _ in range(4)]
+    dx_a = ops.bn_backward(dy.cuda().to(torch.bfloat16).reshape(-1), xg, M, C, HW, mean, invstd, gamma.cuda(),
+                           beta.cuda(), dgamma=dg[0], dbeta=dg[1], dy_nchw=True)
+    dy_rows = dy.permute(0, 2, 1).reshape(M, C).contiguous()
+    dx_b = ops.bn_backward(dy_rows.cuda().to(torch.bfloat16), xg, M, C, HW, mean, invstd, gamma.cuda(), beta.cuda(),
+                           dgamma=dg[2], dbeta=dg[3])
+    assert torch.equal(dx_a, dx_b)
+    close(dg[0], dg[2].cpu(), 1e-5)
+
+
+@pytest.mark.parametrize("B,D", [(8, 32), (64, 512), (5, 128)])
+def test_embedding_tail(B, D):
+    from vlsfr_amd import ops
+    torch.manual_seed(B * D)
+    fc = torch.randn(B, D) * 3
+    bias, gamma, beta = torch.randn(D) * 0.1, torch.ones(D), torch.randn(D) * 0.1
+    fr, br, ber = fc.clone().requires_grad_(True), bias.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(D), torch.ones(D)
+    e_ref = F.normalize(F.batch_norm(fr + br, rm, rv, gamma, ber, True, 0.1, 1e-5))
+    de = torch.randn(B, D)
+    e_ref.backward(de)
+    rmg, rvg = torch.zeros(D).cuda(), torch.ones(D).cuda()
+    emb, saved = ops.embed_fwd(fc.cuda(), bias.cuda(), gamma.cuda(), beta.cuda(), rmg, rvg)
+    close(emb, e_ref.detach(), 1e-5)
+    close(rmg, rm, 1e-5)
+    close(rvg, rv, 1e-5)
+    dbeta, dfcb = torch.zeros(D).cuda(), torch.zeros(D).cuda()
+    dfc = ops.embed_bwd(de.cuda(), emb, saved, gamma.cuda(), dbeta, dfcb)
+    close(dfc, fr.grad, 1e-2)
+    close(dbeta, ber.grad, 1e-4)

@@ -1,0 +1,470 @@
+// Convolution family of the iResNet / MobileFaceNet backbones on gfx950 MFMA
+// (C-ABI section 5 of include/vlsfr.h).  Replaces the nn.Conv2d calls of reference
+// model/resnet_arcface.py:5-23,36,39,74,120 and nn.Linear at :95 (a 1x1 convolution on a 1x1 map),
+// forward, input-gradient and weight-gradient.
+//
+// Layouts: activations NHWC bf16; weights bf16 [rows][R][S][C] with C fastest ("KRSC" for the forward
+// pass, the [Cin][R][S][Cout] transpose for the input gradient); weight gradients fp32 [Cout][R][S][Cin],
+// which is exactly the memory of a torch.channels_last OIHW parameter.
+//
+// conv_igemm_kernel — implicit GEMM, output-channel on the MFMA row and output pixel on the MFMA
+//   column, so each lane ends with 4 consecutive channels of one pixel (8-byte NHWC stores).
+//   K = (r, s, c) with c fastest; C % 32 == 0, so one 32-deep k-tile never straddles a filter tap and
+//   the gather is "one shifted pixel row per k-tile".  Register-staged double-buffered LDS, one
+//   barrier per k-tile.  mode 0 gathers for the forward pass, mode 1 for the input gradient
+//   (stride-2 taps that do not divide are zero rows).  Optional split-K with fp32 atomic output.
+// conv_wgrad_kernel — dW = dY^T · gather(X): the contraction index is the pixel, which is the
+//   slow axis of both NHWC operands, so both tiles go to LDS pixel-major as they lie in memory and
+//   are read back with ds_read_b64_tr_b16 (hardware transpose).  Split over the pixel range with
+//   fp32 atomics into the (pre-zeroed or accumulating) gradient buffer.
+#include "hip_common.h"
+
+using namespace vlsfr;
+
+namespace {
+
+struct ConvArgs {
+  const u16* x;      // gathered activations [Nimg, H, W, C] bf16
+  const u16* w;      // [Mrows][R][S][C] bf16
+  void* y;           // bf16 [P, Mrows] (splitk == 1) or fp32 [P, Mrows] accumulated atomically
+  int Nimg, H, W, C;
+  int Ho, Wo;        // output pixels P = Nimg * Ho * Wo
+  int Mrows;
+  int R, S, stride, pad;
+  int mode;          // 0: forward gather, 1: input-gradient gather
+  int splitk;
+  int out_f32;
+};
+
+__device__ __forceinline__ int swz4(int row) {
+  // chunk swizzle for 64-byte LDS rows read with ds_read_b128 by (row = lane & 15, chunk = lane >> 4):
+  // XOR the 16-byte chunk index with g[(row >> 2) & 3], g = {0, 2, 3, 1} — conflict-free for every
+  // 16-lane service group of the instruction.
+  return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int MT = BM / 32;   // 16-row MFMA tiles per wave along output channels
+  constexpr int NT = BN / 32;   // along pixels
+  constexpr int ACH = BM * 4 / 256;   // 16-byte chunks per thread, weight tile
+  constexpr int BCH = BN * 4 / 256;   // pixel tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 64];
+  char* sA = smem;
+  char* sB = smem + 2 * BM * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = a.Nimg * a.Ho * a.Wo;
+  const int K = a.R * a.S * a.C;
+  const int m0 = blockIdx.y * BM;
+  const int p0 = blockIdx.x * BN;
+  const int nkt = K / 32;
+  // split-K range of k-tiles
+  const int per = (nkt + a.splitk - 1) / a.splitk;
+  const int kt0 = blockIdx.z * per;
+  const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
+  if (kt0 >= kt1) return;
+
+  // ---- per-thread staging coordinates
+  int b_n[BCH], b_h[BCH], b_w[BCH];
+  bool b_ok[BCH];
+#pragma unroll
+  for (int u = 0; u < BCH; ++u) {
+    const int prow = (tid >> 2) + 64 * u;
+    const int p = p0 + prow;
+    b_ok[u] = p < P;
+    const int pp = b_ok[u] ? p : 0;
+    const int n = pp / (a.Ho * a.Wo);
+    const int rem = pp - n * a.Ho * a.Wo;
+    const int ho = rem / a.Wo;
+    const int wo = rem - ho * a.Wo;
+    b_n[u] = n;
+    if (a.mode == 0) {
+      b_h[u] = ho * a.stride - a.pad;
+      b_w[u] = wo * a.stride - a.pad;
+    } else {
+      b_h[u] = ho + a.pad;
+      b_w[u] = wo + a.pad;
+    }
+  }
+  const int chunk = tid & 3;
+  uint4 ra[ACH], rb[BCH];
+
+  auto issue = [&](int kt) {
+    const int k0 = kt * 32;
+    const int tap = k0 / a.C;
+    const int c0 = k0 - tap * a.C;
+    const int r = tap / a.S;
+    const int s = tap - r * a.S;
+#pragma unroll
+    for (int u = 0; u < ACH; ++u) {
+      const int row = (tid >> 2) + 64 * u;
+      const int m = m0 + row;
+      if (m < a.Mrows) ra[u] = *(const uint4*)(a.w + (size_t)m * K + k0 + chunk * 8);
+      else ra[u] = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      int hi, wi;
+      bool ok = b_ok[u];
+      if (a.mode == 0) {
+        hi = b_h[u] + r;
+        wi = b_w[u] + s;
+      } else {
+        const int th = b_h[u] - r, tw = b_w[u] - s;
+        if (a.stride == 2) {
+          ok = ok && !((th | tw) & 1);
+          hi = th >> 1;
+          wi = tw >> 1;
+        } else {
+          hi = th;
+          wi = tw;
+        }
+      }
+      ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      if (ok) rb[u] = *(const uint4*)(a.x + (((size_t)b_n[u] * a.H + hi) * a.W + wi) * a.C + c0 + chunk * 8);
+      else rb[u] = make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < ACH; ++u) {
+      const int row = (tid >> 2) + 64 * u;
+      *(uint4*)(sA + buf * BM * 64 + row * 64 + ((chunk ^ swz4(row)) << 4)) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      const int row = (tid >> 2) + 64 * u;
+      *(uint4*)(sB + buf * BN * 64 + row * 64 + ((chunk ^ swz4(row)) << 4)) = rb[u];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(kt0);
+  stage(0);
+  __syncthreads();
+  const int rd_off = r16 * 64 + ((h ^ swz4(r16)) << 4);
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(kt + 1);
+    bf16x8 fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      fa[i] = *(const bf16x8*)(sA + buf * BM * 64 + (wm * (BM / 2) + i * 16) * 64 + rd_off);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      fb[j] = *(const bf16x8*)(sB + buf * BN * 64 + (wn * (BN / 2) + j * 16) * 64 + rd_off);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    if (kt + 1 < kt1) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int p = p0 + wn * (BN / 2) + j * 16 + r16;
+    if (p >= P) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h;
+      if (m >= a.Mrows) continue;
+      if (a.out_f32) {
+        float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
+        if (a.splitk > 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
+        } else {
+          *(f32x4*)dst = acc[i][j];
+        }
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
+        *(bf16x4*)((u16*)a.y + (size_t)p * a.Mrows + m) = o;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const u16* dy;     // [P, Cout] bf16
+  const u16* x;      // [Nimg, H, W, C] bf16 (forward input)
+  float* dw;         // [Cout][R][S][C] fp32, accumulated atomically
+  int Nimg, H, W, C;
+  int Ho, Wo, Cout;
+  int R, S, stride, pad;
+  int splitk;
+  int n_coltiles;    // column tiles per tap = ceil(C / BN)
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int MT = BM / 32;
+  constexpr int NT = BN / 32;
+  constexpr int RSA = BM * 2 + 32;   // LDS row strides (bytes): +32 keeps the transposed reads conflict-free
+  constexpr int RSB = BN * 2 + 32;
+  constexpr int ACH = 32 * (BM / 8) / 256 > 0 ? 32 * (BM / 8) / 256 : 1;   // 16-byte chunks per thread
+  constexpr int BCH = 32 * (BN / 8) / 256 > 0 ? 32 * (BN / 8) / 256 : 1;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * (RSA + RSB)];
+  char* sA = smem;
+  char* sB = smem + 2 * 32 * RSA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = a.Nimg * a.Ho * a.Wo;
+  const int m0 = blockIdx.y * BM;
+  const int tap = blockIdx.x / a.n_coltiles;
+  const int c0 = (blockIdx.x - tap * a.n_coltiles) * BN;
+  const int r = tap / a.S, s = tap - r * a.S;
+  const int nkt = (P + 31) / 32;
+  const int per = (nkt + a.splitk - 1) / a.splitk;
+  const int kt0 = blockIdx.z * per;
+  const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
+  if (kt0 >= kt1) return;
+
+  uint4 ra[ACH], rb[BCH];
+  auto issue = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < ACH; ++u) {
+      const int e = tid + 256 * u;
+      const int prow = e / (BM / 8), ch = e % (BM / 8);
+      const int p = kt * 32 + prow;
+      const bool ok = (e < 32 * (BM / 8)) && p < P && (m0 + ch * 8) < a.Cout;
+      ra[u] = ok ? *(const uint4*)(a.dy + (size_t)p * a.Cout + m0 + ch * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      const int e = tid + 256 * u;
+      const int prow = e / (BN / 8), ch = e % (BN / 8);
+      const int p = kt * 32 + prow;
+      bool ok = (e < 32 * (BN / 8)) && p < P && (c0 + ch * 8) < a.C;
+      const int pp = ok ? p : 0;
+      const int n = pp / (a.Ho * a.Wo);
+      const int rem = pp - n * a.Ho * a.Wo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      const int hi = ho * a.stride - a.pad + r;
+      const int wi = wo * a.stride - a.pad + s;
+      ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+      rb[u] = ok ? *(const uint4*)(a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.C + c0 + ch * 8)
+                 : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < ACH; ++u) {
+      const int e = tid + 256 * u;
+      if (e < 32 * (BM / 8)) *(uint4*)(sA + buf * 32 * RSA + (e / (BM / 8)) * RSA + (e % (BM / 8)) * 16) = ra[u];
+    }
+#pragma unroll
+    for (int u = 0; u < BCH; ++u) {
+      const int e = tid + 256 * u;
+      if (e < 32 * (BN / 8)) *(uint4*)(sB + buf * 32 * RSB + (e / (BN / 8)) * RSB + (e % (BN / 8)) * 16) = rb[u];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(kt0);
+  stage(0);
+  __syncthreads();
+  // transposed block reads: lane (q = r16 >> 2, p4 = r16 & 3) of group h addresses tile row 4h + q
+  // (and + 16), columns 4 p4 .. 4 p4 + 3 of a 16-column block; k order = 16 (e >> 2) + 4h + (e & 3)
+  // on both operands.
+  const int trow = 4 * h + (r16 >> 2);
+  const int tcol = (r16 & 3) * 8;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int buf = (kt - kt0) & 1;
+    if (kt + 1 < kt1) issue(kt + 1);
+    bf16x8 fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      char* base = sA + buf * 32 * RSA + (wm * (BM / 2) + i * 16) * 2 + tcol;
+      short4v v0 = lds_read_tr16(base + trow * RSA);
+      short4v v1 = lds_read_tr16(base + (trow + 16) * RSA);
+      short __attribute__((ext_vector_type(8))) vs = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      fa[i] = __builtin_bit_cast(bf16x8, vs);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      char* base = sB + buf * 32 * RSB + (wn * (BN / 2) + j * 16) * 2 + tcol;
+      short4v v0 = lds_read_tr16(base + trow * RSB);
+      short4v v1 = lds_read_tr16(base + (trow + 16) * RSB);
+      short __attribute__((ext_vector_type(8))) vs = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      fb[j] = __builtin_bit_cast(bf16x8, vs);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    if (kt + 1 < kt1) stage(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- epilogue: D[row = cout 4h + e][col = ci r16]
+  const int K = a.R * a.S * a.C;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h + e;
+      if (m >= a.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = c0 + wn * (BN / 2) + j * 16 + r16;
+        if (c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+      }
+    }
+  }
+}
+
+int conv_check(const vlsfr_conv_desc* d, const char* who) {
+  if (!d) return fail(VLSFR_EINVAL, "%s: null descriptor", who);
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0)
+    return fail(VLSFR_EINVAL, "%s: non-positive dimension", who);
+  if (d->Cin % 32 != 0) return fail(VLSFR_EINVAL, "%s: Cin must be a multiple of 32 (got %d)", who, d->Cin);
+  if (d->Cout % 8 != 0) return fail(VLSFR_EINVAL, "%s: Cout must be a multiple of 8 (got %d)", who, d->Cout);
+  if (!((d->R == 3 && d->S == 3 && d->pad == 1) || (d->R == 1 && d->S == 1 && d->pad == 0)))
+    return fail(VLSFR_EINVAL, "%s: only 3x3/pad 1 and 1x1/pad 0 filters are covered", who);
+  if (d->stride != 1 && d->stride != 2) return fail(VLSFR_EINVAL, "%s: stride must be 1 or 2", who);
+  return VLSFR_OK;
+}
+
+inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+template <int BM, int BN>
+void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
+  dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), grid, dim3(256), 0, st, a);
+}
+
+int run_igemm(ConvArgs a, hipStream_t st) {
+  const int P = a.Nimg * a.Ho * a.Wo;
+  // tile choice: the 128x128 tile unless the channel count or the pixel count is small
+  const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
+  if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);
+  else if (a.Mrows >= 128) launch_igemm<128, 64>(a, P, st);
+  else launch_igemm<64, 128>(a, P, st);
+  VLSFR_HIP_CHECK_LAUNCH("conv_igemm launch");
+  return VLSFR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk, int32_t out_f32,
+                     void* stream) {
+  int rc = conv_check(d, "vlsfr_conv2d_fwd");
+  if (rc) return rc;
+  if (!x || !w || !y) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd: null buffer");
+  if (splitk < 1) splitk = 1;
+  if (splitk > 1 && !out_f32) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd: split-K needs the fp32 (atomic) output");
+  ConvArgs a;
+  a.x = (const u16*)x;
+  a.w = (const u16*)w;
+  a.y = y;
+  a.Nimg = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.C = d->Cin;
+  a.Ho = out_dim(d->H, d->R, d->stride, d->pad);
+  a.Wo = out_dim(d->W, d->S, d->stride, d->pad);
+  a.Mrows = d->Cout;
+  a.R = d->R;
+  a.S = d->S;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.mode = 0;
+  a.splitk = splitk;
+  a.out_f32 = out_f32;
+  return run_igemm(a, (hipStream_t)stream);
+}
+
+int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream) {
+  int rc = conv_check(d, "vlsfr_conv2d_dgrad");
+  if (rc) return rc;
+  if (!dy || !wT || !dx) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad: null buffer");
+  if (d->Cout % 32 != 0) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad: Cout must be a multiple of 32");
+  ConvArgs a;
+  a.x = (const u16*)dy;
+  a.w = (const u16*)wT;
+  a.y = dx;
+  a.Nimg = d->N;
+  a.H = out_dim(d->H, d->R, d->stride, d->pad);   // the gathered tensor is dY
+  a.W = out_dim(d->W, d->S, d->stride, d->pad);
+  a.C = d->Cout;
+  a.Ho = d->H;                                    // one output "pixel" per input position
+  a.Wo = d->W;
+  a.Mrows = d->Cin;
+  a.R = d->R;
+  a.S = d->S;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.mode = 1;
+  a.splitk = 1;
+  a.out_f32 = 0;
+  return run_igemm(a, (hipStream_t)stream);
+}
+
+int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
+                       void* stream) {
+  int rc = conv_check(d, "vlsfr_conv2d_wgrad");
+  if (rc) return rc;
+  if (!dy || !x || !dw) return fail(VLSFR_EINVAL, "vlsfr_conv2d_wgrad: null buffer");
+  WgradArgs a;
+  a.dy = (const u16*)dy;
+  a.x = (const u16*)x;
+  a.dw = dw;
+  a.Nimg = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.C = d->Cin;
+  a.Ho = out_dim(d->H, d->R, d->stride, d->pad);
+  a.Wo = out_dim(d->W, d->S, d->stride, d->pad);
+  a.Cout = d->Cout;
+  a.R = d->R;
+  a.S = d->S;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  const int P = a.Nimg * a.Ho * a.Wo;
+  const int nkt = (P + 31) / 32;
+  const bool wide = d->Cin >= 128;
+  const int BN = wide ? 128 : 64;
+  const int BM = d->Cout >= 128 ? 128 : 64;
+  a.n_coltiles = (d->Cin + BN - 1) / BN;
+  const int tiles = a.n_coltiles * d->R * d->S * ((d->Cout + BM - 1) / BM);
+  if (splitk <= 0) {   // aim at ~1024 workgroups, at least 8 k-tiles each
+    splitk = (1024 + tiles - 1) / tiles;
+    if (splitk > nkt / 8) splitk = nkt / 8;
+    if (splitk < 1) splitk = 1;
+  }
+  a.splitk = splitk;
+  dim3 grid(a.n_coltiles * d->R * d->S, (d->Cout + BM - 1) / BM, splitk);
+  hipStream_t st = (hipStream_t)stream;
+  if (BM == 128 && BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
+  else if (BM == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
+  else if (BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+  VLSFR_HIP_CHECK_LAUNCH("conv_wgrad launch");
+  return VLSFR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+"""Thin ctypes wrappers over the per-operator device entry points of libvlsfr.so (sections 5-6 of
+include/vlsfr.h).  Used by the per-kernel parity tests; the training path drives the same kernels
+through the native backbone executor (backbone.py / csrc/iresnet.cpp) instead of one Python call
+per operator."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("N", "H", "W", "Cin", "Cout", "R", "S", "stride", "pad")]
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _call(name, *args):
+    fn = getattr(_lib.lib(), name)
+    fn.restype = ctypes.c_int
+    _lib.check(fn(*args), name)
+
+
+def out_hw(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def cast_weight(w_f32, rows, taps, C, Kp=None, transpose=True):
+    """w_f32: fp32 device tensor whose memory is [rows][taps][C].  Returns (w bf16 [rows, Kp], wT bf16
+    [C, taps, rows] or None)."""
+    Kp = Kp or taps * C
+    wb = torch.empty(rows, Kp, dtype=torch.bfloat16, device=w_f32.device)
+    wT = torch.empty(C, taps, rows, dtype=torch.bfloat16, device=w_f32.device) if transpose else None
+    _call("vlsfr_cast_weight", _p(w_f32), _p(wb), _p(wT), ctypes.c_int32(rows), ctypes.c_int32(taps),
+          ctypes.c_int32(C), ctypes.c_int32(Kp), _st())
+    return wb, wT
+
+
+def conv2d_fwd(x, w, desc, splitk=1, out_f32=False):
+    Ho, Wo = out_hw(desc.H, desc.R, desc.stride, desc.pad), out_hw(desc.W, desc.S, desc.stride, desc.pad)
+    if out_f32:
+        y = torch.zeros(desc.N, Ho, Wo, desc.Cout, dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty(desc.N, Ho, Wo, desc.Cout, dtype=torch.bfloat16, device=x.device)
+    _call("vlsfr_conv2d_fwd", ctypes.byref(desc), _p(x), _p(w), _p(y), ctypes.c_int32(splitk),
+          ctypes.c_int32(int(out_f32)), _st())
+    return y
+
+
+def conv2d_dgrad(dy, wT, desc):
+    dx = torch.empty(desc.N, desc.H, desc.W, desc.Cin, dtype=torch.bfloat16, device=dy.device)
+    _call("vlsfr_conv2d_dgrad", ctypes.byref(desc), _p(dy), _p(wT), _p(dx), _st())
+    return dx
+
+
+def conv2d_wgrad(dy, x, desc, dw=None, splitk=0):
+    if dw is None:
+        dw = torch.zeros(desc.Cout, desc.R, desc.S, desc.Cin, dtype=torch.float32, device=x.device)
+    _call("vlsfr_conv2d_wgrad", ctypes.byref(desc), _p(dy), _p(x), _p(dw), ctypes.c_int32(splitk), _st())
+    return dw
+
+
+def bn_stats(x, M, C):
+    sums = torch.zeros(2, C, dtype=torch.float32, device=x.device)
+    _call("vlsfr_bn_stats", _p(x), ctypes.c_int64(M), ctypes.c_int32(C), _p(sums), _st())
+    return sums
+
+
+def bn_apply(x, M, C, HW, sums, gamma, beta, slope=None, residual=None, running_mean=None, running_var=None,
+             out_nchw=False, eps=1e-5, momentum=0.1):
+    y = torch.empty(M * C, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    _call("vlsfr_bn_apply", _p(x), _p(y), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW), _p(sums),
+          _p(gamma), _p(beta), _p(slope), _p(residual), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+          ctypes.c_float(eps), ctypes.c_float(momentum), ctypes.c_int32(int(out_nchw)), _st())
+    return y, mean, invstd
+
+
+def bn_backward(dy, x, M, C, HW, mean, invstd, gamma, beta, slope=None, dx_add=None, dgamma=None, dbeta=None,
+                dslope=None, dy_nchw=False):
+    dx = torch.empty(M * C, dtype=torch.bfloat16, device=x.device)
+    red = torch.empty(3, C, dtype=torch.float32, device=x.device)
+    _call("vlsfr_bn_backward", _p(dy), _p(x), _p(dx), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW),
+          _p(mean), _p(invstd), _p(gamma), _p(beta), _p(slope), _p(red), _p(dx_add), _p(dgamma), _p(dbeta),
+          _p(dslope), ctypes.c_int32(int(dy_nchw)), _st())
+    return dx
+
+
+def stem_im2col(x_nchw):
+    N, _, H, W = x_nchw.shape
+    out = torch.empty(N * H * W, 32, dtype=torch.bfloat16, device=x_nchw.device)
+    _call("vlsfr_stem_im2col", _p(x_nchw), _p(out), ctypes.c_int32(N), ctypes.c_int32(H), ctypes.c_int32(W), _st())
+    return out
+
+
+def embed_fwd(fc, fc_bias, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    B, D = fc.shape
+    mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=fc.device)
+    z, xhat, invstd, emb, inv_norm = mk(B, D), mk(B, D), mk(D), mk(B, D), mk(B)
+    _call("vlsfr_embed_fwd", _p(fc), _p(fc_bias), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(z),
+          _p(xhat), _p(invstd), _p(emb), _p(inv_norm), ctypes.c_int32(B), ctypes.c_int32(D), ctypes.c_float(eps),
+          ctypes.c_float(momentum), _st())
+    return emb, (z, xhat, invstd, inv_norm)
+
+
+def embed_bwd(demb, emb, saved, gamma, dbeta, dfc_bias):
+    z, xhat, invstd, inv_norm = saved
+    B, D = emb.shape
+    dz = torch.empty(B, D, dtype=torch.float32, device=emb.device)
+    dfc = torch.empty(B, D, dtype=torch.bfloat16, device=emb.device)
+    _call("vlsfr_embed_bwd", _p(demb), _p(emb), _p(inv_norm), _p(xhat), _p(invstd), _p(gamma), _p(dz), _p(dfc),
+          _p(dbeta), _p(dfc_bias), ctypes.c_int32(B), ctypes.c_int32(D), _st())
+    return dfc
