@@ -214,6 +214,48 @@ int vlsfr_cast_weight(const float* w, void* w_bf16, void* wT_bf16, int32_t rows,
 int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, void* stream);
 int vlsfr_unpad_add(const float* src, float* dst, int32_t rows, int32_t Ksrc, int32_t Kdst, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 7. iResNet backbone executor (host object, device work).  One call = one whole forward or
+ *    backward pass of reference model/resnet_arcface.py:58-152 (IResNet.forward, training mode)
+ *    enqueued on the caller's stream.  `params` / `grads` are host arrays of device pointers in
+ *    the registration order of the reference module (named_parameters(): conv1.weight,
+ *    bn1.weight, bn1.bias, prelu.weight, layer1.0.bn1.weight, ... fc.weight, fc.bias,
+ *    features.weight, features.bias); `running` holds (running_mean, running_var) device
+ *    pointers per BatchNorm in the same order (NULL array = do not update).  Convolution weights
+ *    are fp32 in channels_last memory ([Cout][R][S][Cin]); gradients are ACCUMULATED (+=).
+ *    wcache: bf16 operand copies (vlsfr_iresnet_prepare_weights, whenever the weights change);
+ *    ctx: activations + statistics of one forward pass, consumed by the matching backward;
+ *    scratch: transient.  All three are caller-allocated device buffers of the queried sizes.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_iresnet vlsfr_iresnet;
+int vlsfr_iresnet_create(const int32_t* layers /*[4]*/, int32_t feat_dim, int32_t batch, int32_t image_hw,
+                         vlsfr_iresnet** out);
+void vlsfr_iresnet_destroy(vlsfr_iresnet* n);
+int32_t vlsfr_iresnet_num_params(const vlsfr_iresnet* n);
+int32_t vlsfr_iresnet_num_bn(const vlsfr_iresnet* n);
+size_t vlsfr_iresnet_wcache_bytes(const vlsfr_iresnet* n);
+size_t vlsfr_iresnet_ctx_bytes(const vlsfr_iresnet* n);
+size_t vlsfr_iresnet_scratch_bytes(const vlsfr_iresnet* n);
+int vlsfr_iresnet_prepare_weights(const vlsfr_iresnet* n, const float* const* params, void* wcache, void* stream);
+/* x_nchw: fp32 [B,3,HW,HW] (loader contract, util/lmdb_loader.py:127); emb_out: fp32 [B, feat_dim] */
+int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params,
+                          float* const* running, const void* wcache, void* ctx, void* scratch, float* emb_out,
+                          void* stream);
+int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const float* const* params,
+                           float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 8. Parameter sweeps (device), one launch over all tensors.
+ *    vlsfr_sgd_nesterov replaces torch.optim.SGD.step as built by optim/optimizer.py:148-150
+ *    (momentum buffer starts at zero == torch's first-step clone); vlsfr_ema replaces
+ *    FFC._momentum_update_gallery (ffc.py:139-145).
+ *    table_dev: int64 device array, one row per chunk (<= 65536 elements, 16-byte aligned starts):
+ *      sgd: {param, grad, momentum_buffer, count}      ema: {gallery, probe, count}
+ * ---------------------------------------------------------------------------------------- */
+int vlsfr_sgd_nesterov(const int64_t* table_dev, int32_t n_chunks, float lr, float momentum,
+                       float weight_decay, int32_t nesterov, void* stream);
+int vlsfr_ema(const int64_t* table_dev, int32_t n_chunks, float m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,147 @@
+"""Whole training step on the GPU (native iResNet executor + fused head + fused SGD/EMA, through the
+drop-in FFC / get_optim_scheduler surface) against the reference's golden step vectors (float64
+arithmetic of the reference itself) and against the float64 oracle.
+
+Tolerances: the backbone computes with bf16 operands / fp32 accumulation, so
+embeddings are compared by cosine (>= 0.999), the loss to rtol 2e-2, gradient tensors by relative
+L2 error, LRU / queue_position state exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbones_ref as bb
+from tests.golden import common
+from tests.test_oracle_golden import G, build_oracle_from_step, sample
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def min_cos(a, b):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float(torch.nn.functional.cosine_similarity(a, b, dim=1).min())
+
+
+def build_ffc(z, net_type, precise_head=True):
+    from vlsfr_amd.ffc import FFC
+    Q, D, B, seed = [int(v) for v in z["meta"]]
+    m = FFC(net_type, D, Q, 32.0, "Arc", 0.5, 0.99, precise_head=precise_head)
+    sd0, _ = bb.make_backbone(net_type, D, layers=(1, 1, 1, 1) if net_type == "irtiny" else None)
+    sd = common.fill_state(sd0, seed)
+    m.probe_net.load_state_dict(sd, strict=True)
+    m.gallery_net.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    m.queue.copy_(torch.from_numpy(z["queue_warm"]).float())
+    m.lru.restore(list(zip(z["lru_warm_keys"].tolist(), z["lru_warm_slots"].tolist())))
+    m._state().qp[:] = z["qp_warm"].astype(np.uint8)
+    inp = common.step_inputs(seed, Q, D, B)
+    x, y = common.images_from_u8(inp["xu8"]).cuda(), common.images_from_u8(inp["yu8"]).cuda()
+    return m, x, y, torch.from_numpy(inp["xl"]), torch.from_numpy(inp["yl"])
+
+
+def test_irtiny_step_matches_reference_golden():
+    from vlsfr_amd.optim import get_optim_scheduler
+    z = np.load(os.path.join(G, "step_irtiny.npz"))
+    m, x, y, xl, yl = build_ffc(z, "irtiny")
+    cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
+               milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])
+    opt, sched = get_optim_scheduler([p for p in m.parameters() if p.requires_grad], cfg)
+    sched.update(0, 0.0)
+    embs = []
+    hook = m.probe_net.register_forward_hook(lambda mod, i, o: embs.append(o.detach().cpu()))
+    opt.zero_grad()
+    loss = m(x, y, xl, yl)
+    loss.backward()
+    hook.remove()
+    torch.cuda.synchronize()
+    # embeddings, loss
+    assert min_cos(embs[0], z["emb_probe_x"]) >= 0.999
+    assert min_cos(embs[1], z["emb_probe_y"]) >= 0.999
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=2e-2)
+    # gradients
+    names = [str(n) for n in z["grad_names"]]
+    pn = dict(m.probe_net.named_parameters())
+    gn = np.asarray([float(pn[n].grad.norm()) for n in names])
+    big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
+    np.testing.assert_allclose(gn[big], z["grad_norms"][big], rtol=8e-2)
+    for key in z.files:
+        if key.startswith("grad/"):
+            want = z[key]
+            if np.abs(want).max() < 1e-6:
+                continue    # bias in front of a BatchNorm: exactly zero gradient in exact arithmetic
+            got = sample(pn[key[5:]].grad.detach().cpu().numpy())
+            assert rel_l2(got, want) < 0.1, (key, rel_l2(got, want))
+    # optimizer step + EMA
+    opt.step()
+    torch.cuda.synchronize()
+    gp = dict(m.gallery_net.named_parameters())
+    for key in z.files:
+        if key.startswith("after/"):
+            got = sample(pn[key[6:]].detach().cpu().numpy())
+            assert rel_l2(got, z[key]) < 0.1, (key, rel_l2(got, z[key]))   # lr * gradient dominates: same bound as the gradients
+        elif key.startswith("gallery_after/"):
+            np.testing.assert_allclose(sample(gp[key[14:]].detach().cpu().numpy()), z[key], rtol=1e-5, atol=1e-6)
+        elif key.startswith("buf/"):
+            got = dict(m.probe_net.named_buffers())[key[4:]].cpu().numpy()
+            np.testing.assert_allclose(got, z[key], rtol=3e-2, atol=3e-3)
+    # pool and allocator state
+    assert [k for k, _ in m.lru.state_dict()] == z["lru_final_keys"].tolist()
+    assert [v for _, v in m.lru.state_dict()] == z["lru_final_slots"].tolist()
+    assert m.queue_position_dict.values() == z["qp_final"].astype(int).tolist()
+    qf, qw = m.queue.cpu().numpy(), z["queue_final"]
+    changed = np.abs(qw - z["queue_warm"]).max(axis=2) > 0
+    assert min_cos(qf[changed], qw[changed]) >= 0.999           # rows written by the gallery net
+    np.testing.assert_array_equal(qf[~changed], qw[~changed].astype(np.float32))
+
+
+def test_ir18_two_steps_vs_oracle():
+    """A deeper net (ir18), two consecutive steps, against the float64 oracle: loss trajectory,
+    LRU / queue_position state, embedding cosine."""
+    from vlsfr_amd.ffc import FFC
+    from vlsfr_amd.optim.fused import FusedSGD
+    from oracle import ffc_ref
+    torch.manual_seed(0)
+    Q, D, B = 96, 64, 8
+    o = ffc_ref.FFCRef("ir18", D, Q, 32.0, "AM", 0.4, 0.99, dtype=torch.float64)
+    sd = common.fill_state({k: v.detach() for k, v in o.probe.items()}, 77)
+    o.probe = {k: (v.double().requires_grad_(bb.trainable(k)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    o.gallery = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    m = FFC("ir18", D, Q, 32.0, "AM", 0.4, 0.99, precise_head=True)
+    m.probe_net.load_state_dict(sd)
+    m.gallery_net.load_state_dict(sd)
+    m = m.cuda()
+    m.queue.copy_(o.queue.float())
+    opt = FusedSGD([p for p in m.parameters() if p.requires_grad], 0.05, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    rng = np.random.default_rng(9)
+    bufs = None
+    for step in range(2):
+        xu8, yu8 = common.synth_images_u8(rng, B), common.synth_images_u8(rng, B)
+        ids = rng.choice(50, size=B // 2, replace=False)
+        xl = torch.from_numpy(np.concatenate([ids, rng.integers(0, 50, B // 2)]).astype(np.int64))
+        yl = torch.from_numpy(np.concatenate([ids, rng.integers(0, 50, B // 2)]).astype(np.int64))
+        x, y = common.images_from_u8(xu8), common.images_from_u8(yu8)
+        params = o.parameters()
+        for p in params:
+            p.grad = None
+        lo = o.forward(x.double(), y.double(), xl, yl)
+        lo.backward()
+        bufs = ffc_ref.sgd_nesterov_step_ref(params, [p.grad for p in params], bufs or [None] * len(params), 0.05)
+        opt.zero_grad()
+        lg = m(x.cuda(), y.cuda(), xl, yl)
+        lg.backward()
+        opt.step()
+        np.testing.assert_allclose(float(lg.detach()), float(lo.detach()), rtol=3e-2)
+        assert m.lru.state_dict() == o.lru.state_dict()
+        assert m.queue_position_dict.values() == o.qp
+    w_o = o.probe["layer2.0.conv1.weight"].detach().numpy()
+    w_g = m.probe_net.layer2[0].conv1.weight.detach().cpu().numpy()
+    # lr * gradient dominates the two-step weight change, and bf16 gradients of this deep, batch-8
+    # train-mode-BN stack deviate 3-10 % from float64 (scripts/diag_grad_profile.py shows the error
+    # growing smoothly from 1 % at the head to 10 % at the stem, no jump at any layer type)
+    assert rel_l2(w_g, w_o) < 0.25

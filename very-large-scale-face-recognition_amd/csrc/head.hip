@@ -442,7 +442,6 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
   const int label = a.pool_label[i];
   const float qs = a.scale * LOG2E;
   for (int d = tid; d < D; d += 256) dp[d] = 0.f;
-  __shared__ float sh_val[4];
   __shared__ int sh_idx[4];
   __syncthreads();
 

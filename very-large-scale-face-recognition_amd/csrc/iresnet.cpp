@@ -1,0 +1,411 @@
+// Native executor of the iResNet backbone (C-ABI section 7 of include/vlsfr.h): one call runs the
+// whole forward (or backward) pass by enqueueing the gfx950 kernels of conv.hip / norm.hip on the
+// caller's stream — no per-operator host round trip.  Architecture and semantics: reference
+// model/resnet_arcface.py:26-55 (IBasicBlock: BN -> 3x3 -> BN -> PReLU -> 3x3(stride) -> BN (+ shortcut))
+// and :58-152 (stem conv/BN/PReLU at full resolution, 4 stages whose first block is stride 2 with a
+// 1x1-s2 + BN shortcut, BN -> flatten -> fc -> BN1d(weight frozen) -> L2 normalise), in training
+// mode.  Parameter / buffer order = registration order of the reference module (named_parameters()).
+#include <cstdint>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "common_host.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f;
+constexpr float BN_MOM = 0.1f;
+
+struct Bn {
+  int C;
+  int p_w, p_b;      // parameter indices (gamma, beta)
+  int p_slope;       // PReLU parameter index or -1
+  int run;           // index of the (running_mean, running_var) pair
+  size_t off_sums;   // ctx: fp32 [2, C]
+  size_t off_mean;   // ctx: fp32 [C]
+  size_t off_invstd; // ctx: fp32 [C]
+};
+
+struct Conv {
+  vlsfr_conv_desc d;
+  int p_w;
+  size_t off_wb, off_wT;   // wcache (bytes)
+};
+
+struct Block {
+  int cin, planes, stride, H, W, Ho, Wo;
+  Bn bn1, bn2, bn3, bnd;
+  Conv conv1, conv2, convd;
+  bool has_ds;
+  // ctx activations (byte offsets, bf16)
+  size_t a1, c1, a2, c2, cs, out;
+};
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+struct vlsfr_iresnet {
+  int layers[4];
+  int D, B, HW0;
+  int n_params = 0, n_bn = 0;
+  // stem
+  Conv stem;   // 1x1 over the 32-wide im2col rows
+  Bn stem_bn;
+  size_t off_cols, off_c0, off_a0;
+  std::vector<Block> blocks;
+  Bn bn_last;
+  size_t off_flat;   // bf16 [B, 25088] in the reference's flatten order
+  Conv fc;
+  int p_fc_b, p_feat_w, p_feat_b, run_feat;
+  size_t off_fcout, off_z, off_xhat, off_feat_invstd, off_emb, off_invnorm;
+  size_t sums_begin, sums_end;
+  size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0;
+  size_t max_act = 0;   // largest activation tensor in bytes
+
+  size_t take_ctx(size_t bytes) {
+    size_t o = ctx_bytes;
+    ctx_bytes += align_up(bytes);
+    return o;
+  }
+  size_t take_w(size_t bytes) {
+    size_t o = wcache_bytes;
+    wcache_bytes += align_up(bytes);
+    return o;
+  }
+  Bn make_bn(int C, bool prelu_after_in_order) {
+    (void)prelu_after_in_order;
+    Bn b;
+    b.C = C;
+    b.p_w = n_params++;
+    b.p_b = n_params++;
+    b.p_slope = -1;
+    b.run = n_bn++;
+    b.off_sums = b.off_mean = b.off_invstd = 0;
+    return b;
+  }
+  Conv make_conv(int N, int H, int W, int cin, int cout, int k, int stride) {
+    Conv c;
+    c.d = vlsfr_conv_desc{N, H, W, cin, cout, k, k, stride, k == 3 ? 1 : 0};
+    c.p_w = n_params++;
+    const size_t bytes = (size_t)cout * k * k * cin * 2;
+    c.off_wb = take_w(bytes);
+    c.off_wT = take_w(bytes);
+    return c;
+  }
+  void bn_ctx(Bn& b) {
+    b.off_mean = take_ctx((size_t)b.C * 4);
+    b.off_invstd = take_ctx((size_t)b.C * 4);
+  }
+};
+
+namespace {
+
+using vlsfr::fail;
+
+int build(vlsfr_iresnet* n) {
+  const int B = n->B, S = n->HW0;
+  // ---- parameter order: registration order of the reference module
+  n->stem.d = vlsfr_conv_desc{B, S, S, 32, 64, 1, 1, 1, 0};
+  n->stem.p_w = n->n_params++;                      // conv1.weight
+  n->stem.off_wb = n->take_w((size_t)64 * 32 * 2);
+  n->stem.off_wT = 0;
+  n->stem_bn = n->make_bn(64, true);                // bn1.weight, bn1.bias
+  n->stem_bn.p_slope = n->n_params++;               // prelu.weight
+  int cin = 64, H = S;
+  const int planes_of[4] = {64, 128, 256, 512};
+  for (int li = 0; li < 4; ++li) {
+    for (int bi = 0; bi < n->layers[li]; ++bi) {
+      Block b;
+      b.cin = cin;
+      b.planes = planes_of[li];
+      b.stride = bi == 0 ? 2 : 1;
+      b.H = b.W = H;
+      b.Ho = b.Wo = (H + 2 - 3) / b.stride + 1;
+      b.bn1 = n->make_bn(cin, false);
+      b.conv1 = n->make_conv(B, H, H, cin, b.planes, 3, 1);
+      b.bn2 = n->make_bn(b.planes, true);
+      b.bn2.p_slope = n->n_params++;
+      b.conv2 = n->make_conv(B, H, H, b.planes, b.planes, 3, b.stride);
+      b.bn3 = n->make_bn(b.planes, false);
+      b.has_ds = bi == 0;
+      if (b.has_ds) {
+        b.convd = n->make_conv(B, H, H, cin, b.planes, 1, b.stride);
+        b.bnd = n->make_bn(b.planes, false);
+      }
+      n->blocks.push_back(b);
+      cin = b.planes;
+      H = b.Ho;
+    }
+  }
+  if (H * H * 512 % 32 != 0) return fail(VLSFR_EINVAL, "iresnet: unsupported image size");
+  n->bn_last = n->make_bn(512, false);              // bn2.*
+  const int Kfc = 512 * H * H;
+  n->fc.d = vlsfr_conv_desc{B, 1, 1, Kfc, n->D, 1, 1, 1, 0};
+  n->fc.p_w = n->n_params++;                        // fc.weight
+  n->fc.off_wb = n->take_w((size_t)n->D * Kfc * 2);
+  n->fc.off_wT = n->take_w((size_t)n->D * Kfc * 2);
+  n->p_fc_b = n->n_params++;                        // fc.bias
+  n->p_feat_w = n->n_params++;                      // features.weight (frozen)
+  n->p_feat_b = n->n_params++;                      // features.bias
+  n->run_feat = n->n_bn++;
+
+  // ---- ctx layout: statistics first (one memset clears every sums slot), then activations
+  n->sums_begin = n->ctx_bytes;
+  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)2 * b.C * 4); };
+  sums(n->stem_bn);
+  for (auto& b : n->blocks) {
+    sums(b.bn1);
+    sums(b.bn2);
+    sums(b.bn3);
+    if (b.has_ds) sums(b.bnd);
+  }
+  sums(n->bn_last);
+  n->off_fcout = n->take_ctx((size_t)B * n->D * 4);   // zeroed with the sums (split-K accumulates into it)
+  n->sums_end = n->ctx_bytes;
+  n->bn_ctx(n->stem_bn);
+  for (auto& b : n->blocks) {
+    n->bn_ctx(b.bn1);
+    n->bn_ctx(b.bn2);
+    n->bn_ctx(b.bn3);
+    if (b.has_ds) n->bn_ctx(b.bnd);
+  }
+  n->bn_ctx(n->bn_last);
+  const size_t P0 = (size_t)B * S * S;
+  n->off_cols = n->take_ctx(P0 * 32 * 2);
+  n->off_c0 = n->take_ctx(P0 * 64 * 2);
+  n->off_a0 = n->take_ctx(P0 * 64 * 2);
+  n->max_act = P0 * 64 * 2;
+  for (auto& b : n->blocks) {
+    const size_t pin = (size_t)B * b.H * b.W, pout = (size_t)B * b.Ho * b.Wo;
+    b.a1 = n->take_ctx(pin * b.cin * 2);
+    b.c1 = n->take_ctx(pin * b.planes * 2);
+    b.a2 = n->take_ctx(pin * b.planes * 2);
+    b.c2 = n->take_ctx(pout * b.planes * 2);
+    b.cs = b.has_ds ? n->take_ctx(pout * b.planes * 2) : 0;
+    b.out = n->take_ctx(pout * b.planes * 2);
+    if (pin * b.planes * 2 > n->max_act) n->max_act = pin * b.planes * 2;
+    if (pin * b.cin * 2 > n->max_act) n->max_act = pin * b.cin * 2;
+  }
+  n->off_flat = n->take_ctx((size_t)B * Kfc * 2);
+  n->off_z = n->take_ctx((size_t)B * n->D * 4);
+  n->off_xhat = n->take_ctx((size_t)B * n->D * 4);
+  n->off_feat_invstd = n->take_ctx((size_t)n->D * 4);
+  n->off_emb = n->take_ctx((size_t)B * n->D * 4);
+  n->off_invnorm = n->take_ctx((size_t)B * 4);
+  // scratch: 3 activation-sized gradient buffers + the shortcut tensor + small fp32 scratch
+  n->scratch_bytes = 4 * align_up(n->max_act) + align_up((size_t)3 * 2048 * 4) + align_up((size_t)64 * 32 * 4) +
+                     align_up((size_t)B * n->D * 4) + align_up((size_t)B * n->D * 2);
+  return VLSFR_OK;
+}
+
+struct Scratch {
+  char* g[3];
+  char* idn;
+  float* red;
+  float* stem_dw;
+  float* dz;
+  char* dfc;
+};
+
+Scratch carve(const vlsfr_iresnet* n, void* scratch) {
+  Scratch s;
+  char* p = (char*)scratch;
+  const size_t a = align_up(n->max_act);
+  for (int i = 0; i < 3; ++i) s.g[i] = p + i * a;
+  s.idn = p + 3 * a;
+  p += 4 * a;
+  s.red = (float*)p;
+  p += align_up((size_t)3 * 2048 * 4);
+  s.stem_dw = (float*)p;
+  p += align_up((size_t)64 * 32 * 4);
+  s.dz = (float*)p;
+  p += align_up((size_t)n->B * n->D * 4);
+  s.dfc = p;
+  return s;
+}
+
+#define RUN(expr)             \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != VLSFR_OK) return rc__; \
+  } while (0)
+
+int bn_forward(const vlsfr_iresnet* n, const Bn& b, const void* x, void* y, int64_t M, int HW, const void* residual,
+               int out_nchw, const float* const* params, float* const* running, char* ctx, void* st) {
+  float* sums = (float*)(ctx + b.off_sums);
+  RUN(vlsfr_bn_stats(x, M, b.C, sums, st));
+  float* rm = running ? running[2 * b.run] : nullptr;
+  float* rv = running ? running[2 * b.run + 1] : nullptr;
+  return vlsfr_bn_apply(x, y, M, b.C, HW, sums, params[b.p_w], params[b.p_b],
+                        b.p_slope >= 0 ? params[b.p_slope] : nullptr, residual, (float*)(ctx + b.off_mean),
+                        (float*)(ctx + b.off_invstd), rm, rv, BN_EPS, BN_MOM, out_nchw, st);
+}
+
+int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M, int HW, const void* dx_add,
+                int dy_nchw, const float* const* params, float* const* grads, char* ctx, float* red, void* st) {
+  return vlsfr_bn_backward(dy, x, dx, M, b.C, HW, (const float*)(ctx + b.off_mean), (const float*)(ctx + b.off_invstd),
+                           params[b.p_w], params[b.p_b], b.p_slope >= 0 ? params[b.p_slope] : nullptr, red, dx_add,
+                           grads[b.p_w], grads[b.p_b], b.p_slope >= 0 ? grads[b.p_slope] : nullptr, dy_nchw, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vlsfr_iresnet_create(const int32_t* layers, int32_t feat_dim, int32_t batch, int32_t image_hw, vlsfr_iresnet** out) {
+  if (!layers || !out || feat_dim <= 0 || feat_dim % 8 || batch <= 0 || image_hw <= 0 || image_hw % 16)
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_create: need feat_dim %% 8 == 0 and image size %% 16 == 0");
+  for (int i = 0; i < 4; ++i)
+    if (layers[i] < 1) return fail(VLSFR_EINVAL, "vlsfr_iresnet_create: every stage needs at least one block");
+  vlsfr_iresnet* n = new (std::nothrow) vlsfr_iresnet();
+  if (!n) return fail(VLSFR_ENOMEM, "vlsfr_iresnet_create: out of memory");
+  std::memcpy(n->layers, layers, sizeof(n->layers));
+  n->D = feat_dim;
+  n->B = batch;
+  n->HW0 = image_hw;
+  int rc = build(n);
+  if (rc != VLSFR_OK) {
+    delete n;
+    return rc;
+  }
+  *out = n;
+  return VLSFR_OK;
+}
+
+void vlsfr_iresnet_destroy(vlsfr_iresnet* n) { delete n; }
+int32_t vlsfr_iresnet_num_params(const vlsfr_iresnet* n) { return n ? n->n_params : -1; }
+int32_t vlsfr_iresnet_num_bn(const vlsfr_iresnet* n) { return n ? n->n_bn : -1; }
+size_t vlsfr_iresnet_wcache_bytes(const vlsfr_iresnet* n) { return n ? n->wcache_bytes : 0; }
+size_t vlsfr_iresnet_ctx_bytes(const vlsfr_iresnet* n) { return n ? n->ctx_bytes : 0; }
+size_t vlsfr_iresnet_scratch_bytes(const vlsfr_iresnet* n) { return n ? n->scratch_bytes : 0; }
+
+int vlsfr_iresnet_prepare_weights(const vlsfr_iresnet* n, const float* const* params, void* wcache, void* st) {
+  if (!n || !params || !wcache) return fail(VLSFR_EINVAL, "vlsfr_iresnet_prepare_weights: null argument");
+  char* wc = (char*)wcache;
+  RUN(vlsfr_cast_weight(params[n->stem.p_w], wc + n->stem.off_wb, nullptr, 64, 1, 27, 32, st));
+  auto cast = [&](const Conv& c) {
+    return vlsfr_cast_weight(params[c.p_w], wc + c.off_wb, wc + c.off_wT, c.d.Cout, c.d.R * c.d.S, c.d.Cin,
+                             c.d.R * c.d.S * c.d.Cin, st);
+  };
+  for (const auto& b : n->blocks) {
+    RUN(cast(b.conv1));
+    RUN(cast(b.conv2));
+    if (b.has_ds) RUN(cast(b.convd));
+  }
+  return cast(n->fc);
+}
+
+int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params,
+                          float* const* running, const void* wcache, void* ctx_v, void* scratch, float* emb_out,
+                          void* st) {
+  if (!n || !x_nchw || !params || !wcache || !ctx_v || !scratch || !emb_out)
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_forward: null argument");
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  Scratch sc = carve(n, scratch);
+  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward: memset: %s", hipGetErrorString(e));
+  const int B = n->B, S = n->HW0;
+  // stem (resnet_arcface.py:140-142)
+  RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, B, S, S, st));
+  RUN(vlsfr_conv2d_fwd(&n->stem.d, ctx + n->off_cols, wc + n->stem.off_wb, ctx + n->off_c0, 1, 0, st));
+  RUN(bn_forward(n, n->stem_bn, ctx + n->off_c0, ctx + n->off_a0, (int64_t)B * S * S, S * S, nullptr, 0, params,
+                 running, ctx, st));
+  const char* cur = ctx + n->off_a0;
+  for (const auto& b : n->blocks) {   // IBasicBlock.forward, resnet_arcface.py:44-55
+    const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
+    RUN(bn_forward(n, b.bn1, cur, ctx + b.a1, Min, b.H * b.W, nullptr, 0, params, running, ctx, st));
+    RUN(vlsfr_conv2d_fwd(&b.conv1.d, ctx + b.a1, wc + b.conv1.off_wb, ctx + b.c1, 1, 0, st));
+    RUN(bn_forward(n, b.bn2, ctx + b.c1, ctx + b.a2, Min, b.H * b.W, nullptr, 0, params, running, ctx, st));
+    RUN(vlsfr_conv2d_fwd(&b.conv2.d, ctx + b.a2, wc + b.conv2.off_wb, ctx + b.c2, 1, 0, st));
+    const void* idn = cur;
+    if (b.has_ds) {
+      RUN(vlsfr_conv2d_fwd(&b.convd.d, cur, wc + b.convd.off_wb, ctx + b.cs, 1, 0, st));
+      RUN(bn_forward(n, b.bnd, ctx + b.cs, sc.idn, Mout, b.Ho * b.Wo, nullptr, 0, params, running, ctx, st));
+      idn = sc.idn;
+    }
+    RUN(bn_forward(n, b.bn3, ctx + b.c2, ctx + b.out, Mout, b.Ho * b.Wo, idn, 0, params, running, ctx, st));
+    cur = ctx + b.out;
+  }
+  // bn2 -> flatten -> fc -> features -> normalise (resnet_arcface.py:147-151)
+  const Block& last = n->blocks.back();
+  const int HWl = last.Ho * last.Wo;
+  RUN(bn_forward(n, n->bn_last, cur, ctx + n->off_flat, (int64_t)B * HWl, HWl, nullptr, 1, params, running, ctx, st));
+  const int Kfc = n->fc.d.Cin;
+  int splitk = (Kfc / 32) / 12;
+  if (splitk < 1) splitk = 1;
+  if (splitk > 64) splitk = 64;
+  RUN(vlsfr_conv2d_fwd(&n->fc.d, ctx + n->off_flat, wc + n->fc.off_wb, ctx + n->off_fcout, splitk, 1, st));
+  float* rm = running ? running[2 * n->run_feat] : nullptr;
+  float* rv = running ? running[2 * n->run_feat + 1] : nullptr;
+  RUN(vlsfr_embed_fwd((const float*)(ctx + n->off_fcout), params[n->p_fc_b], params[n->p_feat_w], params[n->p_feat_b],
+                      rm, rv, (float*)(ctx + n->off_z), (float*)(ctx + n->off_xhat),
+                      (float*)(ctx + n->off_feat_invstd), (float*)(ctx + n->off_emb), (float*)(ctx + n->off_invnorm),
+                      B, n->D, BN_EPS, BN_MOM, st));
+  e = hipMemcpyAsync(emb_out, ctx + n->off_emb, (size_t)B * n->D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward: copy: %s", hipGetErrorString(e));
+  return VLSFR_OK;
+}
+
+int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const float* const* params, float* const* grads,
+                           const void* wcache, void* ctx_v, void* scratch, void* st) {
+  if (!n || !demb || !params || !grads || !wcache || !ctx_v || !scratch)
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_backward: null argument");
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  Scratch sc = carve(n, scratch);
+  const int B = n->B, S = n->HW0;
+  const Block& last = n->blocks.back();
+  const int HWl = last.Ho * last.Wo;
+  // embedding tail, fc
+  RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
+                      (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd),
+                      params[n->p_feat_w], sc.dz, sc.dfc, grads[n->p_feat_b], grads[n->p_fc_b], B, n->D, st));
+  RUN(vlsfr_conv2d_wgrad(&n->fc.d, sc.dfc, ctx + n->off_flat, grads[n->fc.p_w], 0, st));
+  char* dflat = sc.g[0];
+  RUN(vlsfr_conv2d_dgrad(&n->fc.d, sc.dfc, wc + n->fc.off_wT, dflat, st));
+  char* dcur = sc.g[1];
+  RUN(bn_backward(n->bn_last, dflat, ctx + last.out, dcur, (int64_t)B * HWl, HWl, nullptr, 1, params, grads, ctx,
+                  sc.red, st));
+  // blocks in reverse; dcur rotates through the three gradient buffers
+  int cur_i = 1;
+  for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
+    const Block& b = n->blocks[k];
+    const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
+    const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
+    char* t1 = sc.g[(cur_i + 1) % 3];
+    char* t2 = sc.g[(cur_i + 2) % 3];
+    const char* dout = sc.g[cur_i];
+    // main branch
+    RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, sc.red, st));
+    RUN(vlsfr_conv2d_wgrad(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, st));
+    RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
+    RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, sc.red, st));   // d c1
+    RUN(vlsfr_conv2d_wgrad(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, st));
+    RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, st));                 // d a1 (in t2)
+    const char* add = dout;
+    if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
+      RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, sc.red, st));
+      RUN(vlsfr_conv2d_wgrad(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, st));
+      RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
+      add = sc.idn;
+    }
+    // d x_in = bn1 backward of d a1, plus the shortcut gradient
+    RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, sc.red, st));
+    cur_i = (cur_i + 1) % 3;   // t1 is the new dcur
+  }
+  // stem
+  char* dc0 = sc.g[(cur_i + 1) % 3];
+  RUN(bn_backward(n->stem_bn, sc.g[cur_i], ctx + n->off_c0, dc0, (int64_t)B * S * S, S * S, nullptr, 0, params, grads,
+                  ctx, sc.red, st));
+  hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_conv2d_wgrad(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, st));
+  return vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, st);
+}
+
+}  // extern "C"

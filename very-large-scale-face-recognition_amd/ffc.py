@@ -1,0 +1,108 @@
+"""FFC module — same constructor, attributes and call contract as the reference ``ffc.FFC``
+(ffc.py:10-267): probe net (trained) + gallery net (EMA copy, frozen), Dynamic Class Pool
+``queue[2, Q, D]``, LRU slot allocator, ``queue_position_dict``, AM / Arc / SV margin losses with
+the hard-negative term, and the rollback + commit double pass of ``forward``.
+
+What runs where: backbones -> native iResNet executor (model/iresnet.py); pool bookkeeping ->
+native LRU (lru.py / head.py); both pool contractions, margins, cross-entropy, top-k and dL/dp ->
+the fused head kernels (head.py); EMA -> one fused pass over the parameters.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+from torch.nn import Module
+
+from . import _lib
+from .head import DcpHead, QueuePositionView
+from .model import create_net
+
+
+class FFC(Module):
+    def __init__(self, net_type, feat_dim, queue_size=7409, scale=32.0, loss_type='AM', margin=0.4, momentum=0.99,
+                 neg_margin=0.25, pretrained_model_path=None, num_class=None, precise_head=False):
+        super(FFC, self).__init__()
+        assert loss_type in ('AM', 'Arc', 'SV')                       # ffc.py:17
+        self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.probe_net = create_net(net_type, feat_dim=feat_dim, fp16=True)      # ffc.py:22-23
+        self.gallery_net = create_net(net_type, feat_dim=feat_dim, fp16=True)
+        self.register_buffer('queue', F.normalize(torch.rand(2, queue_size, feat_dim), dim=2))   # ffc.py:29-30
+        self.queue_size = queue_size
+        self.feat_dim = feat_dim
+        self.scale = scale
+        self.margin = margin
+        self.loss_type = loss_type
+        self.neg_margin = neg_margin
+        self.register_buffer('mask', torch.zeros(self.queue_size, 1))  # ffc.py:45 (state-dict parity; unused here)
+        self.m = momentum
+        self.mask_svfc = 1.2
+        self.hard_neg = min(max(int(self.queue_size * 0.0002), 3), 10)
+        self.precise_head = precise_head
+        self._head = None
+        self._head_qptr = None
+        self.__dict__['_bootstrap_head'] = DcpHeadState(queue_size)
+        for param_p, param_g in zip(self.probe_net.parameters(), self.gallery_net.parameters()):   # ffc.py:53-55
+            param_g.data.copy_(param_p.data)
+            param_g.requires_grad = False
+
+    # -- reference attributes read by main.py:85 ----------------------------------------------------
+    @property
+    def lru(self):
+        return self._state().lru
+
+    @property
+    def queue_position_dict(self):
+        return QueuePositionView(self._state().qp)
+
+    def _state(self):
+        return self._head if self._head is not None else self.__dict__['_bootstrap_head']
+
+    def _ensure_head(self):
+        """(Re)binds the native head to the device pool tensor (after .cuda() / load_state_dict)."""
+        q = self.queue
+        if not q.is_cuda:
+            raise _lib.VlsfrError("FFC.forward: move the module to the GPU first (.cuda()); there is no CPU path")
+        if self._head is None or self._head_qptr != q.data_ptr():
+            if not q.is_contiguous():
+                self.queue = q = q.contiguous()
+            old = self._state()
+            head = DcpHead(q, self.scale, self.margin, self.loss_type, precise=self.precise_head)
+            head.lru, head.qp = old.lru, old.qp          # keep the allocator state across re-binds
+            self._head, self._head_qptr = head, q.data_ptr()
+        return self._head
+
+    @torch.no_grad()
+    def _momentum_update_gallery(self):                               # ffc.py:139-145
+        from .optim.fused import ema_update
+        ema_update(list(self.gallery_net.parameters()), list(self.probe_net.parameters()), self.m)
+        self.gallery_net.weights_dirty = True
+
+    def forward_impl(self, p_data, g_data, probe_label, gallery_label):          # ffc.py:153-204
+        head = self._ensure_head()
+        p = self.probe_net(p_data)
+        with torch.no_grad():
+            g = self.gallery_net(g_data)
+        return head.run_pass(p, g, probe_label, gallery_label, transactional=False)
+
+    def forward_impl_rollback(self, p_data, g_data, probe_label, gallery_label):  # ffc.py:208-260
+        head = self._ensure_head()
+        p = self.probe_net(p_data)
+        with torch.no_grad():
+            self._momentum_update_gallery()
+            g = self.gallery_net(g_data)
+        return head.run_pass(p, g, probe_label, gallery_label, transactional=True)
+
+    def forward(self, x, y, x_label, y_label):                        # ffc.py:264-267
+        loss2 = self.forward_impl_rollback(x, y, x_label, y_label)
+        loss1 = self.forward_impl(y, x, y_label, x_label)
+        return loss1 + loss2
+
+
+class DcpHeadState(object):
+    """Allocator state that exists before the pool tensor reaches the device."""
+
+    def __init__(self, queue_size):
+        import numpy as np
+        from .lru import LRU
+        self.lru = LRU(queue_size)
+        self.qp = np.zeros(queue_size, dtype=np.uint8)
