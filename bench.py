@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Headline benchmark: faces/sec of the FFC training step (zero_grad -> forward -> backward ->
+SGD step) on N MI355X of one node.  Metric / config: BASELINE.json (`configs[1]` at N = 1:
+iResNet50 + 1M identities, FFC DCP, bf16 MFMA operands).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement): value = whole-job faces/sec with the
+inputs resident in HBM, plus `roofline` (dominant kernel family, timed live with HIP events on its
+launch stream) and `cpu_baseline` (the oracle's CPU restatement on a bounded sample, rank 0, N = 1).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+
+
+def host_threads():
+    """Cores this process may actually use (the GPU box gives one GPU's share, not the whole host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def note(msg):
+    sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - T0, msg))
+    sys.stderr.flush()
+
+
+T0 = time.perf_counter()
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--net", default="ir50")
+    ap.add_argument("--batch", type=int, default=64, help="--batch_size of the reference: rows of x and of y per GPU")
+    ap.add_argument("--identities", type=int, default=1 << 20)
+    ap.add_argument("--queue", type=int, default=0, help="pool slots (0 = one per identity, full residency)")
+    ap.add_argument("--feat", type=int, default=512)
+    ap.add_argument("--loss", default="Arc")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def synth_batch(rng, B, n_id, device):
+    """uniform uint8 pixels -> (v - 127.5) * 0.0078125 fp32 NCHW; id half shares labels
+    between the two views, instance half draws them independently (main.py:53-60)."""
+    def imgs():
+        u8 = torch.from_numpy(rng.integers(0, 256, size=(B, 3, 112, 112), dtype=np.uint8)).to(device)
+        return (u8.float() - 127.5) * 0.0078125
+    h = B // 2
+    ids = rng.choice(n_id, size=h, replace=False)
+    xl = np.concatenate([ids, rng.integers(0, n_id, size=B - h)]).astype(np.int64)
+    yl = np.concatenate([ids, rng.integers(0, n_id, size=B - h)]).astype(np.int64)
+    return imgs(), imgs(), torch.from_numpy(xl), torch.from_numpy(yl)
+
+
+def cpu_baseline(args):
+    """The oracle's CPU restatement (PyTorch CPU fp32, all host cores) of the same step on a bounded
+    sample: same backbone and feature size, reduced batch and pool so it finishes in ~10-30 s."""
+    from oracle import ffc_ref
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    B, Q = args.cpu_batch, 1 << 17
+    gen = torch.Generator().manual_seed(0)
+    o = ffc_ref.FFCRef(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, gen=gen)
+    o.lru.restore([(k, k) for k in range(4096)])          # a few thousand resident identities (O(n) oracle LRU)
+    rng = np.random.default_rng(0)
+    bufs = [None] * len(o.parameters())
+    t_total, faces = 0.0, 0
+    for step in range(args.cpu_steps + 1):
+        x, y, xl, yl = synth_batch(rng, B, 4096, "cpu")
+        note("cpu baseline step %d" % step)
+        t0 = time.perf_counter()
+        for p in o.parameters():
+            p.grad = None
+        loss = o.forward(x, y, xl, yl)
+        loss.backward()
+        ps = o.parameters()
+        bufs = ffc_ref.sgd_nesterov_step_ref(ps, [p.grad for p in ps], bufs, 0.1)
+        dt = time.perf_counter() - t0
+        if step > 0:                                      # first step = warm-up
+            t_total += dt
+            faces += 2 * B
+    return dict(value=faces / t_total, unit="faces/sec", cores=threads, kind="port",
+                sample="%s D=%d, pool 131072 slots, batch %d, %d timed steps, fp32 PyTorch-CPU oracle" %
+                       (args.net, args.feat, B, args.cpu_steps))
+
+
+def main():
+    args = parse()
+    torch.set_num_threads(host_threads())
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import vlsfr_amd  # noqa: F401
+    from vlsfr_amd import _lib
+    from vlsfr_amd.ffc import FFC
+    from vlsfr_amd.optim import get_optim_scheduler
+    from vlsfr_amd.parallel import DataParallelFFC
+
+    Q = args.queue or args.identities
+    torch.manual_seed(1234)                                   # identical initial weights on every rank
+    model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99).cuda()
+    n_res = min(Q, args.identities)
+    model.lru.restore(list(zip(range(n_res), range(n_res))))  # steady state: the pool is full (lru.py:113)
+    cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
+               milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])     # config/optim_config
+    opt, sched = get_optim_scheduler([p for p in model.parameters() if p.requires_grad], cfg)
+    sched.update(0, 0.0)
+    step_model = DataParallelFFC(model, dist) if world > 1 else model
+    rng = np.random.default_rng(1234 + rank)
+    B = args.batch
+    batches = [synth_batch(rng, B, args.identities, dev) for _ in range(min(4, args.steps + args.warmup))]
+
+    def one_step(i):
+        x, y, xl, yl = batches[i % len(batches)]
+        opt.zero_grad()
+        loss = step_model(x, y, xl, yl)
+        loss.backward()
+        if world > 1:
+            step_model.reduce_gradients()
+        opt.step()
+        return loss
+
+    L = _lib.lib()
+    note("model on device, pool %d slots; warm-up" % Q)
+    for i in range(args.warmup):
+        one_step(i)
+        torch.cuda.synchronize()
+        note("warm-up step %d done" % i)
+    if dist is not None:
+        dist.barrier()
+    L.vlsfr_profile_reset()
+    L.vlsfr_profile_enable(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    L.vlsfr_profile_enable(0)
+    note("timed region done: %.3f s for %d steps" % (dt, args.steps))
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    fams = {}
+    for fam, name in ((0, "conv_igemm_kernel"), (1, "conv_wgrad_kernel")):
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        L.vlsfr_profile_collect.restype = ctypes.c_int
+        _lib.check(L.vlsfr_profile_collect(ctypes.c_int32(fam), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
+        fams[name] = (ms.value, fl.value, n.value)
+    L.vlsfr_profile_reset()
+    if rank != 0:
+        return
+    dom = max(fams, key=lambda k: fams[k][0])
+    ms, fl, n = fams[dom]
+    achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, launches=int(n),
+                    avg_launch_us=round(ms * 1e3 / max(n, 1), 2),
+                    share_of_step=round(ms / (dt * 1e3), 3),
+                    other={k: dict(total_ms=round(v[0], 2), tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
+                                   launches=int(v[2])) for k, v in fams.items() if k != dom})
+    faces = world * 2 * B * args.steps
+    out = {
+        "metric": "faces/sec (whole node) at %s-identity FFC, %s" % (
+            "%dM" % (args.identities >> 20) if args.identities >= (1 << 20) else str(args.identities), args.net),
+        "value": round(faces / dt, 2), "unit": "faces/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
+                               "(2 x %d faces per step per GPU), SGD-nesterov, 112x112 synthetic images" %
+                               (args.net, args.identities, Q, args.feat, args.loss, B, B),
+                   "parallelism": "dp%d" % world, "loss": float(loss.detach())},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

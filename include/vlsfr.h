@@ -139,6 +139,9 @@ typedef struct vlsfr_head_cfg {
   int32_t hard_neg;
   int32_t precise;
   int32_t n_chunks;
+  int32_t n_rows_total;   /* 0 or B: single process.  > B: this call holds B probe rows of a batch of
+                             n_rows_total rows spread over ranks (g, the special table, n_pos and the
+                             loss normalisers refer to the whole batch; pool_label to these B rows) */
 } vlsfr_head_cfg;
 
 size_t vlsfr_head_workspace_bytes(const vlsfr_head_cfg* cfg);
@@ -255,6 +258,16 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
 int vlsfr_sgd_nesterov(const int64_t* table_dev, int32_t n_chunks, float lr, float momentum,
                        float weight_decay, int32_t nesterov, void* stream);
 int vlsfr_ema(const int64_t* table_dev, int32_t n_chunks, float m, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 9. Measurement support: while enabled, every launch of the convolution kernel families is
+ *    bracketed by HIP events on its own stream (family 0: conv_igemm = forward + input gradient,
+ *    family 1: conv_wgrad).  vlsfr_profile_collect sums elapsed time, algorithmic FLOPs
+ *    (2 * pixels * Cout * R*S*Cin per launch) and launch count.  Used by bench.py's roofline leg.
+ * ---------------------------------------------------------------------------------------- */
+void vlsfr_profile_enable(int32_t on);
+int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops, int64_t* launches);
+void vlsfr_profile_reset(void);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,9 @@ def lib():
             raise VlsfrError(
                 "libvlsfr.so not found at %s — build it first (python -c 'import __graft_entry__ as g; "
                 "g.build()'); this package has no CPU / eager fallback" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime: load it first so that libvlsfr.so binds to the
+        # same libamdhip64 (one runtime per process, shared streams and device pointers)
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib

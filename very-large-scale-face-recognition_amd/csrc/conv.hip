@@ -17,11 +17,44 @@
 //   slow axis of both NHWC operands, so both tiles go to LDS pixel-major as they lie in memory and
 //   are read back with ds_read_b64_tr_b16 (hardware transpose).  Split over the pixel range with
 //   fp32 atomics into the (pre-zeroed or accumulating) gradient buffer.
+#include <vector>
+
 #include "hip_common.h"
 
 using namespace vlsfr;
 
 namespace {
+
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around
+// every launch of one kernel family while profiling is enabled.
+struct ProfRec {
+  hipEvent_t a, b;
+  double flops;
+  int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  ProfRec r;
+  ProfScope(hipStream_t s, int family, double flops) : st(s), on(g_prof_on) {
+    if (!on) return;
+    r.family = family;
+    r.flops = flops;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+    hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(r.b, st);
+    g_prof.push_back(r);
+  }
+};
 
 struct ConvArgs {
   const u16* x;      // gathered activations [Nimg, H, W, C] bf16
@@ -357,6 +390,7 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
 
 int run_igemm(ConvArgs a, hipStream_t st) {
   const int P = a.Nimg * a.Ho * a.Wo;
+  ProfScope prof(st, 0, 2.0 * P * (double)a.Mrows * a.R * a.S * a.C);
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
   if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);
@@ -369,6 +403,37 @@ int run_igemm(ConvArgs a, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
+
+int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops, int64_t* launches) {
+  if (!total_ms || !total_flops || !launches) return fail(VLSFR_EINVAL, "vlsfr_profile_collect: null argument");
+  double ms = 0, fl = 0;
+  int64_t n = 0;
+  for (auto& r : g_prof) {
+    if (r.family != family) continue;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e != hipSuccess) return hip_fail(e, "vlsfr_profile_collect: hipEventSynchronize");
+    float t = 0.f;
+    e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e != hipSuccess) return hip_fail(e, "vlsfr_profile_collect: hipEventElapsedTime");
+    ms += t;
+    fl += r.flops;
+    ++n;
+  }
+  *total_ms = ms;
+  *total_flops = fl;
+  *launches = n;
+  return VLSFR_OK;
+}
+
+void vlsfr_profile_reset(void) {
+  for (auto& r : g_prof) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+}
 
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk, int32_t out_f32,
                      void* stream) {
@@ -459,6 +524,7 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   a.splitk = splitk;
   dim3 grid(a.n_coltiles * d->R * d->S, (d->Cout + BM - 1) / BM, splitk);
   hipStream_t st = (hipStream_t)stream;
+  ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * d->R * d->S * d->Cin);
   if (BM == 128 && BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
   else if (BM == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
   else if (BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);

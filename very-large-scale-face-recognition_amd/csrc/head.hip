@@ -694,8 +694,9 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   pl->off_o = take(rowsz * pl->DP * 4 * pl->n_sets);
   pl->off_tv = take(rowsz * 4 * KTOP * 4);
   pl->off_ti = take(rowsz * 4 * KTOP * 4);
-  pl->off_cos1 = take((size_t)c->B * 3 * c->B * 4);
-  pl->off_cos2 = take((size_t)c->B * 3 * c->B * 4);
+  const int Bt = c->n_rows_total > c->B ? c->n_rows_total : c->B;   // rows of the whole (multi-rank) batch
+  pl->off_cos1 = take((size_t)c->B * 3 * Bt * 4);
+  pl->off_cos2 = take((size_t)c->B * 3 * Bt * 4);
   pl->off_thr = take((size_t)pl->Bp * 4 * 2);
   pl->off_rowloss = take((size_t)c->B * 2 * 4);
   pl->total = off;
@@ -762,15 +763,16 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   if (rc != VLSFR_OK) return rc;
   if (!p || !g || !queue || !pool_label || !loss_out || !dP || !workspace)
     return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: null argument");
-  if (n_special < 0 || n_special > 3 * cfg->B || (n_special > 0 && (!special_col || !src1 || !src2)))
+  const int Bt = cfg->n_rows_total > cfg->B ? cfg->n_rows_total : cfg->B;
+  if (n_special < 0 || n_special > 3 * Bt || (n_special > 0 && (!special_col || !src1 || !src2)))
     return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: bad special-column table");
-  if (n_pos < 0 || n_pos > cfg->B) return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: n_pos out of range");
+  if (n_pos < 0 || n_pos > Bt) return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: n_pos out of range");
   if (workspace_bytes < pl.total)
     return fail(VLSFR_EINVAL, "vlsfr_head_fwd_bwd: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
   hipStream_t st = (hipStream_t)stream;
   char* ws = (char*)workspace;
   const int B = cfg->B, D = cfg->D;
-  const int n_out = B - n_pos;
+  const int n_out = Bt - n_pos;   // counts are over the whole batch: the loss means are global
   float* cos1 = (float*)(ws + pl.off_cos1);
   float* cos2 = (float*)(ws + pl.off_cos2);
   float* thr = (float*)(ws + pl.off_thr);

@@ -20,7 +20,8 @@ LOSS_TYPES = {"AM": 0, "Arc": 1, "SV": 2}
 class HeadCfg(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("D", ctypes.c_int32), ("Q", ctypes.c_int64),
                 ("loss_type", ctypes.c_int32), ("scale", ctypes.c_float), ("margin", ctypes.c_float),
-                ("hard_neg", ctypes.c_int32), ("precise", ctypes.c_int32), ("n_chunks", ctypes.c_int32)]
+                ("hard_neg", ctypes.c_int32), ("precise", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
+                ("n_rows_total", ctypes.c_int32)]
 
 
 def _stream_ptr():
@@ -90,12 +91,12 @@ class DcpHead(object):
         self._ws_key = None
 
     # -------------------------------------------------------------------------------------------
-    def _cfg(self, B):
+    def _cfg(self, B, B_total=0):
         return HeadCfg(B, self.D, self.Q, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), self.n_chunks)
+                       int(self.precise), self.n_chunks, B_total)
 
     def _workspace(self, cfg, device):
-        key = (cfg.B, str(device))
+        key = (cfg.B, cfg.n_rows_total, str(device))
         if self._ws_key != key:
             self.L.vlsfr_head_workspace_bytes.restype = ctypes.c_size_t
             self.L.vlsfr_head_workspace_bytes.argtypes = [ctypes.POINTER(HeadCfg)]
@@ -129,9 +130,14 @@ class DcpHead(object):
                                          undo[1].ctypes.data, ctypes.byref(plan)), "vlsfr_dcp_undo")
 
     # -------------------------------------------------------------------------------------------
-    def run_pass(self, p, g, probe_label, gallery_label, transactional):
-        """p: [B, D] fp32 device tensor (may require grad); g: [B, D] fp32 device tensor;
-        labels: host int64 sequences / CPU tensors."""
+    def run_pass(self, p, g, probe_label, gallery_label, transactional, row_offset=None):
+        """p: [B, D] fp32 device tensor (may require grad); g: fp32 device tensor of gallery embeddings;
+        labels: host int64 sequences / CPU tensors.
+
+        Single process: g is [B, D] and the labels have B entries.  Data-parallel (row_offset given):
+        g and the labels cover the whole batch of all ranks in rank order, p holds this rank's B
+        rows starting at row_offset; every rank replays the same bookkeeping and pool writes, the
+        returned loss is this rank's share of the global loss (sum over ranks = reference loss)."""
         if not p.is_cuda:
             raise _lib.VlsfrError("DcpHead.run_pass needs device tensors: the head has no CPU path")
         if torch.is_tensor(probe_label):
@@ -139,23 +145,24 @@ class DcpHead(object):
         if torch.is_tensor(gallery_label):
             gallery_label = gallery_label.cpu().numpy()
         B = int(p.shape[0])
-        assert p.shape == (B, self.D) and g.shape == (B, self.D)
+        n = int(g.shape[0])
+        r0 = 0 if row_offset is None else int(row_offset)
+        assert p.shape == (B, self.D) and g.shape == (n, self.D) and r0 + B <= n
         tab, plan, undo = self.assign(probe_label, gallery_label, transactional)
         dev = p.device
         tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
         pd = p.detach().float().contiguous()
         gd = g.detach().float().contiguous()
-        cfg = self._cfg(B)
+        cfg = self._cfg(B, n if n != B else 0)
         ws = self._workspace(cfg, dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         dP = torch.empty(B, self.D, dtype=torch.float32, device=dev)
         base = tab_d.data_ptr()
-        n = B
-        at = lambda k: ctypes.c_void_p(base + 4 * k * n)
+        at = lambda k, extra=0: ctypes.c_void_p(base + 4 * (k * n + extra))
         fn = self.L.vlsfr_head_fwd_bwd
         fn.restype = ctypes.c_int
         rc = fn(ctypes.byref(cfg), ctypes.c_void_p(pd.data_ptr()), ctypes.c_void_p(gd.data_ptr()),
-                ctypes.c_void_p(self.queue.data_ptr()), at(0), at(1), at(4), at(7), ctypes.c_int32(plan.n_special),
+                ctypes.c_void_p(self.queue.data_ptr()), at(0, r0), at(1), at(4), at(7), ctypes.c_int32(plan.n_special),
                 ctypes.c_int32(plan.n_pos), ctypes.c_void_p(loss.data_ptr()), ctypes.c_void_p(dP.data_ptr()),
                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), _stream_ptr())
         _lib.check(rc, "vlsfr_head_fwd_bwd")

@@ -1,0 +1,72 @@
+"""Multi-GPU FFC step: one process per GPU, RCCL (torch.distributed backend "nccl") over xGMI.
+
+The reference has no distributed code; the semantics defined here are
+*result == single-process reference on the rank-order concatenation of all ranks' batches*
+(BatchNorm statistics stay per rank, like DistributedDataParallel without SyncBN):
+
+  * backbones: data parallel — every rank runs its own B rows; parameter gradients are summed
+    with one all-reduce over a flat gradient buffer (the loss normalisers are already global, so the
+    sum is the reference gradient);
+  * Dynamic Class Pool (round 1): replicated — the gallery embeddings g and both label vectors are
+    all-gathered (g over RCCL, the labels over a gloo side group so no device sync is needed), every
+    rank replays the identical LRU bookkeeping and pool writes, and sweeps the pool for its own B
+    probe rows.  No softmax collective is needed in this form; identity-sharding of the pool with a
+    softmax all-reduce is the next step.
+"""
+import numpy as np
+import torch
+
+
+class DataParallelFFC(object):
+    def __init__(self, model, dist):
+        self.m = model
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.cpu_group = dist.new_group(backend="gloo")
+        self._flat = None
+        # identical starting point on every rank
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=0)
+
+    def _gather_labels(self, lab):
+        lab = torch.as_tensor(lab, dtype=torch.int64).cpu().contiguous()
+        out = [torch.empty_like(lab) for _ in range(self.world)]
+        self.dist.all_gather(out, lab, group=self.cpu_group)
+        return torch.cat(out).numpy()
+
+    def _gather_rows(self, g):
+        out = torch.empty(self.world * g.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
+        self.dist.all_gather_into_tensor(out, g.contiguous())
+        return out
+
+    def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
+        m = self.m
+        head = m._ensure_head()
+        p = m.probe_net(p_data)
+        with torch.no_grad():
+            if transactional:
+                m._momentum_update_gallery()
+            g = m.gallery_net(g_data)
+            g_all = self._gather_rows(g)
+        pl = self._gather_labels(probe_label)
+        gl = self._gather_labels(gallery_label)
+        return head.run_pass(p, g_all, pl, gl, transactional, row_offset=self.rank * p.shape[0])
+
+    def __call__(self, x, y, x_label, y_label):
+        loss2 = self._pass(x, y, x_label, y_label, True)      # ffc.py:265
+        loss1 = self._pass(y, x, y_label, x_label, False)     # ffc.py:266
+        return loss1 + loss2
+
+    def reduce_gradients(self):
+        """Sum the probe-net gradients over ranks (one all-reduce on a flat buffer)."""
+        grads = [p.grad for p in self.m.probe_net.parameters() if p.requires_grad and p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        self.dist.all_reduce(flat)
+        for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(s)
+
+    def global_loss(self, loss):
+        t = loss.detach().clone()
+        self.dist.all_reduce(t)
+        return t
