@@ -172,9 +172,12 @@ typedef struct vlsfr_conv_desc {
   int32_t R, S, stride, pad;
 } vlsfr_conv_desc;
 
-/* y: bf16 [N,Ho,Wo,Cout], or fp32 when out_f32 (required for splitk > 1: accumulated atomically) */
+/* y: bf16 [N,Ho,Wo,Cout], or fp32 when out_f32 (required for splitk > 1: accumulated atomically).
+ * stats (optional, bf16 output only): fp32 [VLSFR_BN_REPL][2][Cout] accumulators (pre-zeroed) that
+ * receive the per-channel sum / sum of squares of the rounded outputs — the BatchNorm statistics of
+ * the following layer, fused into the epilogue. */
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk,
-                     int32_t out_f32, void* stream);
+                     int32_t out_f32, float* stats, void* stream);
 int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream);
 /* splitk <= 0: library choice */
 int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
@@ -186,20 +189,29 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
  *    BatchNorm1d + F.normalize embedding tail (:96-98,151) and the layout/precision conversions.
  *    x, y, dy, dx, residual: bf16 [M, C] (NHWC rows), C % 8 == 0; statistics fp32.
  * ---------------------------------------------------------------------------------------- */
-/* sums fp32 [2, C] (sum, sum of squares), pre-zeroed, accumulated atomically */
+/* Per-channel reductions are kept in VLSFR_BN_REPL replicated accumulators (fp32
+ * [VLSFR_BN_REPL][n][C], pre-zeroed by the caller, accumulated atomically) and folded by the
+ * finalize step. */
+#define VLSFR_BN_REPL 32
+/* sums [REPL][2][C]: sum and sum of squares over the M rows of x */
 int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream);
-/* y = prelu(bn(x)) + residual; slope / residual / running_* may be NULL; out_nchw writes y in the
- * [n][c][hw] flatten order of the reference's fc input (HW = rows per image) */
-int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums,
-                   const float* gamma, const float* beta, const float* slope, const void* residual,
-                   float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                   float eps, float momentum, int32_t out_nchw, void* stream);
+/* sums -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale (fp32 [C] each), and the
+ * running statistics update (momentum, unbiased variance) when running_* are given */
+int vlsfr_bn_finalize(const float* sums, int64_t M, int32_t C, const float* gamma, const float* beta,
+                      float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                      float* running_var, float eps, float momentum, void* stream);
+/* y = prelu(x*scale + shift) + residual; slope / residual may be NULL; out_sums (optional): the
+ * statistics [REPL][2][C] of y for the next BatchNorm; out_nchw writes y in the [n][c][hw] flatten
+ * order of the reference's fc input (HW = rows per image) */
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* scale,
+                   const float* shift, const float* slope, const void* residual, float* out_sums,
+                   int32_t out_nchw, void* stream);
 /* dx = d(prelu(bn(x)))/dx applied to dy (+ dx_add); dgamma/dbeta/dslope are accumulated (+=);
- * red: fp32 [3, C] scratch */
+ * red: fp32 [REPL][3][C] pre-zeroed scratch; kcoef: fp32 [3][C] scratch */
 int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      const float* slope, float* red, const void* dx_add, float* dgamma, float* dbeta,
-                      float* dslope, int32_t dy_nchw, void* stream);
+                      const float* slope, float* red, float* kcoef, const void* dx_add, float* dgamma,
+                      float* dbeta, float* dslope, int32_t dy_nchw, void* stream);
 int vlsfr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* e = normalize(bn1d(fc + fc_bias)); all fp32 [B, D] */
 int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, const float* beta,

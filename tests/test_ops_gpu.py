@@ -54,8 +54,13 @@ def test_conv_fwd_dgrad_wgrad(cin, cout, k, stride, pad, hw):
     xg = nhwc(x).cuda().to(torch.bfloat16)
     w_krsc = w.permute(0, 2, 3, 1).contiguous().cuda()            # fp32 [Cout][R][S][Cin]
     wb, wT = ops.cast_weight(w_krsc, cout, k * k, cin)
-    y = ops.conv2d_fwd(xg, wb, d)
+    stats = ops.new_sums(cout, "cuda")
+    y = ops.conv2d_fwd(xg, wb, d, stats=stats)
     close(y.permute(0, 3, 1, 2), bf(y_ref), 1e-2)
+    # fused BatchNorm statistics of the rounded output (sum and sum of squares per channel)
+    yf = y.float().reshape(-1, cout)
+    close(stats.sum(0)[0], yf.sum(0).cpu(), 1e-3)
+    close(stats.sum(0)[1], (yf * yf).sum(0).cpu(), 1e-3)
     dyg = nhwc(dy).cuda().to(torch.bfloat16)
     if cout % 32 == 0:
         dx = ops.conv2d_dgrad(dyg, wT, d)
@@ -128,9 +133,13 @@ def test_bn_prelu_add_fwd_bwd(C, HW, N, prelu, res):
     xg = x.cuda().to(torch.bfloat16)
     sums = ops.bn_stats(xg, M, C)
     rmg, rvg = rm.cuda(), rv.cuda()
+    osums = ops.new_sums(C, "cuda")
     y, mean, invstd = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), slope.cuda() if prelu else None,
-                                   resid.cuda().to(torch.bfloat16) if res else None, rmg, rvg)
+                                   resid.cuda().to(torch.bfloat16) if res else None, rmg, rvg, out_sums=osums)
     close(y.reshape(M, C), bf(out_ref.detach()), 1e-2)
+    yf = y.float().reshape(M, C)
+    close(osums.sum(0)[0], yf.sum(0).cpu(), 1e-3)            # statistics of the output for the next BatchNorm
+    close(osums.sum(0)[1], (yf * yf).sum(0).cpu(), 1e-3)
     close(rmg, rm_ref, 1e-4)
     close(rvg, rv_ref, 1e-4)
     dgamma, dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")

@@ -67,6 +67,7 @@ struct ConvArgs {
   int mode;          // 0: forward gather, 1: input-gradient gather
   int splitk;
   int out_f32;
+  float* stats;      // optional [VLSFR_BN_REPL][2][Mrows] BatchNorm statistics of the rounded output
 };
 
 __device__ __forceinline__ int swz4(int row) {
@@ -204,6 +205,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
+  float cs[MT][4], cq[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int p = p0 + wn * (BN / 2) + j * 16 + r16;
@@ -223,10 +229,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       } else {
         bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (__bf16)acc[i][j][e];
+          const float f = (float)o[e];
+          cs[i][e] += f;
+          cq[i][e] += f * f;
+        }
         *(bf16x4*)((u16*)a.y + (size_t)p * a.Mrows + m) = o;
       }
     }
+  }
+  if (a.stats) {   // fused BatchNorm statistics: reduce over the 16 pixel lanes, one atomic per channel and wave
+    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = cs[i][e], q = cq[i][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h + e;
+        if (r16 == 0 && m < a.Mrows) {
+          atomicAdd(dst + m, s);
+          atomicAdd(dst + a.Mrows + m, q);
+        }
+      }
   }
 }
 
@@ -436,12 +466,13 @@ void vlsfr_profile_reset(void) {
 }
 
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk, int32_t out_f32,
-                     void* stream) {
+                     float* stats, void* stream) {
   int rc = conv_check(d, "vlsfr_conv2d_fwd");
   if (rc) return rc;
   if (!x || !w || !y) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd: null buffer");
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && !out_f32) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd: split-K needs the fp32 (atomic) output");
+  if (stats && out_f32) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd: fused statistics need the bf16 output");
   ConvArgs a;
   a.x = (const u16*)x;
   a.w = (const u16*)w;
@@ -460,6 +491,7 @@ int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, voi
   a.mode = 0;
   a.splitk = splitk;
   a.out_f32 = out_f32;
+  a.stats = stats;
   return run_igemm(a, (hipStream_t)stream);
 }
 
@@ -486,6 +518,7 @@ int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT,
   a.mode = 1;
   a.splitk = 1;
   a.out_f32 = 0;
+  a.stats = nullptr;
   return run_igemm(a, (hipStream_t)stream);
 }
 

@@ -24,9 +24,13 @@ struct Bn {
   int p_w, p_b;      // parameter indices (gamma, beta)
   int p_slope;       // PReLU parameter index or -1
   int run;           // index of the (running_mean, running_var) pair
-  size_t off_sums;   // ctx: fp32 [2, C]
+  size_t off_sums;   // ctx: fp32 [REPL][2][C] statistics accumulators (zeroed at forward start)
   size_t off_mean;   // ctx: fp32 [C]
   size_t off_invstd; // ctx: fp32 [C]
+  size_t off_scale;  // ctx: fp32 [C]
+  size_t off_shift;  // ctx: fp32 [C]
+  size_t off_red;    // ctx: fp32 [REPL][3][C] backward reductions (zeroed at backward start)
+  size_t off_kcoef;  // ctx: fp32 [3][C]
 };
 
 struct Conv {
@@ -62,7 +66,7 @@ struct vlsfr_iresnet {
   Conv fc;
   int p_fc_b, p_feat_w, p_feat_b, run_feat;
   size_t off_fcout, off_z, off_xhat, off_feat_invstd, off_emb, off_invnorm;
-  size_t sums_begin, sums_end;
+  size_t sums_begin, sums_end, red_begin, red_end;
   size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0;
   size_t max_act = 0;   // largest activation tensor in bytes
 
@@ -84,7 +88,7 @@ struct vlsfr_iresnet {
     b.p_b = n_params++;
     b.p_slope = -1;
     b.run = n_bn++;
-    b.off_sums = b.off_mean = b.off_invstd = 0;
+    b.off_sums = b.off_mean = b.off_invstd = b.off_scale = b.off_shift = b.off_red = b.off_kcoef = 0;
     return b;
   }
   Conv make_conv(int N, int H, int W, int cin, int cout, int k, int stride) {
@@ -99,7 +103,11 @@ struct vlsfr_iresnet {
   void bn_ctx(Bn& b) {
     b.off_mean = take_ctx((size_t)b.C * 4);
     b.off_invstd = take_ctx((size_t)b.C * 4);
+    b.off_scale = take_ctx((size_t)b.C * 4);
+    b.off_shift = take_ctx((size_t)b.C * 4);
+    b.off_kcoef = take_ctx((size_t)3 * b.C * 4);
   }
+  void bn_red(Bn& b) { b.off_red = take_ctx((size_t)VLSFR_BN_REPL * 3 * b.C * 4); }
 };
 
 namespace {
@@ -155,7 +163,7 @@ int build(vlsfr_iresnet* n) {
 
   // ---- ctx layout: statistics first (one memset clears every sums slot), then activations
   n->sums_begin = n->ctx_bytes;
-  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)2 * b.C * 4); };
+  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * b.C * 4); };
   sums(n->stem_bn);
   for (auto& b : n->blocks) {
     sums(b.bn1);
@@ -166,6 +174,16 @@ int build(vlsfr_iresnet* n) {
   sums(n->bn_last);
   n->off_fcout = n->take_ctx((size_t)B * n->D * 4);   // zeroed with the sums (split-K accumulates into it)
   n->sums_end = n->ctx_bytes;
+  n->red_begin = n->ctx_bytes;
+  n->bn_red(n->stem_bn);
+  for (auto& b : n->blocks) {
+    n->bn_red(b.bn1);
+    n->bn_red(b.bn2);
+    n->bn_red(b.bn3);
+    if (b.has_ds) n->bn_red(b.bnd);
+  }
+  n->bn_red(n->bn_last);
+  n->red_end = n->ctx_bytes;
   n->bn_ctx(n->stem_bn);
   for (auto& b : n->blocks) {
     n->bn_ctx(b.bn1);
@@ -234,22 +252,24 @@ Scratch carve(const vlsfr_iresnet* n, void* scratch) {
     if (rc__ != VLSFR_OK) return rc__; \
   } while (0)
 
-int bn_forward(const vlsfr_iresnet* n, const Bn& b, const void* x, void* y, int64_t M, int HW, const void* residual,
+// statistics (already accumulated by the producer of x) -> scale/shift, then y = prelu(bn(x)) + residual
+int bn_forward(const Bn& b, const void* x, void* y, int64_t M, int HW, const void* residual, float* out_sums,
                int out_nchw, const float* const* params, float* const* running, char* ctx, void* st) {
-  float* sums = (float*)(ctx + b.off_sums);
-  RUN(vlsfr_bn_stats(x, M, b.C, sums, st));
   float* rm = running ? running[2 * b.run] : nullptr;
   float* rv = running ? running[2 * b.run + 1] : nullptr;
-  return vlsfr_bn_apply(x, y, M, b.C, HW, sums, params[b.p_w], params[b.p_b],
-                        b.p_slope >= 0 ? params[b.p_slope] : nullptr, residual, (float*)(ctx + b.off_mean),
-                        (float*)(ctx + b.off_invstd), rm, rv, BN_EPS, BN_MOM, out_nchw, st);
+  RUN(vlsfr_bn_finalize((const float*)(ctx + b.off_sums), M, b.C, params[b.p_w], params[b.p_b],
+                        (float*)(ctx + b.off_mean), (float*)(ctx + b.off_invstd), (float*)(ctx + b.off_scale),
+                        (float*)(ctx + b.off_shift), rm, rv, BN_EPS, BN_MOM, st));
+  return vlsfr_bn_apply(x, y, M, b.C, HW, (const float*)(ctx + b.off_scale), (const float*)(ctx + b.off_shift),
+                        b.p_slope >= 0 ? params[b.p_slope] : nullptr, residual, out_sums, out_nchw, st);
 }
 
 int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M, int HW, const void* dx_add,
-                int dy_nchw, const float* const* params, float* const* grads, char* ctx, float* red, void* st) {
+                int dy_nchw, const float* const* params, float* const* grads, char* ctx, void* st) {
   return vlsfr_bn_backward(dy, x, dx, M, b.C, HW, (const float*)(ctx + b.off_mean), (const float*)(ctx + b.off_invstd),
-                           params[b.p_w], params[b.p_b], b.p_slope >= 0 ? params[b.p_slope] : nullptr, red, dx_add,
-                           grads[b.p_w], grads[b.p_b], b.p_slope >= 0 ? grads[b.p_slope] : nullptr, dy_nchw, st);
+                           params[b.p_w], params[b.p_b], b.p_slope >= 0 ? params[b.p_slope] : nullptr,
+                           (float*)(ctx + b.off_red), (float*)(ctx + b.off_kcoef), dx_add, grads[b.p_w], grads[b.p_b],
+                           b.p_slope >= 0 ? grads[b.p_slope] : nullptr, dy_nchw, st);
 }
 
 }  // namespace
@@ -310,36 +330,43 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
   hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward: memset: %s", hipGetErrorString(e));
   const int B = n->B, S = n->HW0;
+  auto sums_of = [&](const Bn& b) { return (float*)(ctx + b.off_sums); };
+  // Every BatchNorm's batch statistics are accumulated by the kernel that PRODUCES its input (conv
+  // epilogue or the previous bn_apply), so no tensor is read just to be averaged.
   // stem (resnet_arcface.py:140-142)
   RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, B, S, S, st));
-  RUN(vlsfr_conv2d_fwd(&n->stem.d, ctx + n->off_cols, wc + n->stem.off_wb, ctx + n->off_c0, 1, 0, st));
-  RUN(bn_forward(n, n->stem_bn, ctx + n->off_c0, ctx + n->off_a0, (int64_t)B * S * S, S * S, nullptr, 0, params,
-                 running, ctx, st));
+  RUN(vlsfr_conv2d_fwd(&n->stem.d, ctx + n->off_cols, wc + n->stem.off_wb, ctx + n->off_c0, 1, 0, sums_of(n->stem_bn), st));
+  RUN(bn_forward(n->stem_bn, ctx + n->off_c0, ctx + n->off_a0, (int64_t)B * S * S, S * S, nullptr,
+                 sums_of(n->blocks[0].bn1), 0, params, running, ctx, st));
   const char* cur = ctx + n->off_a0;
-  for (const auto& b : n->blocks) {   // IBasicBlock.forward, resnet_arcface.py:44-55
+  for (size_t k = 0; k < n->blocks.size(); ++k) {   // IBasicBlock.forward, resnet_arcface.py:44-55
+    const Block& b = n->blocks[k];
+    const Bn& next_bn = k + 1 < n->blocks.size() ? n->blocks[k + 1].bn1 : n->bn_last;
     const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
-    RUN(bn_forward(n, b.bn1, cur, ctx + b.a1, Min, b.H * b.W, nullptr, 0, params, running, ctx, st));
-    RUN(vlsfr_conv2d_fwd(&b.conv1.d, ctx + b.a1, wc + b.conv1.off_wb, ctx + b.c1, 1, 0, st));
-    RUN(bn_forward(n, b.bn2, ctx + b.c1, ctx + b.a2, Min, b.H * b.W, nullptr, 0, params, running, ctx, st));
-    RUN(vlsfr_conv2d_fwd(&b.conv2.d, ctx + b.a2, wc + b.conv2.off_wb, ctx + b.c2, 1, 0, st));
+    RUN(bn_forward(b.bn1, cur, ctx + b.a1, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
+    RUN(vlsfr_conv2d_fwd(&b.conv1.d, ctx + b.a1, wc + b.conv1.off_wb, ctx + b.c1, 1, 0, sums_of(b.bn2), st));
+    RUN(bn_forward(b.bn2, ctx + b.c1, ctx + b.a2, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
+    RUN(vlsfr_conv2d_fwd(&b.conv2.d, ctx + b.a2, wc + b.conv2.off_wb, ctx + b.c2, 1, 0, sums_of(b.bn3), st));
     const void* idn = cur;
     if (b.has_ds) {
-      RUN(vlsfr_conv2d_fwd(&b.convd.d, cur, wc + b.convd.off_wb, ctx + b.cs, 1, 0, st));
-      RUN(bn_forward(n, b.bnd, ctx + b.cs, sc.idn, Mout, b.Ho * b.Wo, nullptr, 0, params, running, ctx, st));
+      RUN(vlsfr_conv2d_fwd(&b.convd.d, cur, wc + b.convd.off_wb, ctx + b.cs, 1, 0, sums_of(b.bnd), st));
+      RUN(bn_forward(b.bnd, ctx + b.cs, sc.idn, Mout, b.Ho * b.Wo, nullptr, nullptr, 0, params, running, ctx, st));
       idn = sc.idn;
     }
-    RUN(bn_forward(n, b.bn3, ctx + b.c2, ctx + b.out, Mout, b.Ho * b.Wo, idn, 0, params, running, ctx, st));
+    RUN(bn_forward(b.bn3, ctx + b.c2, ctx + b.out, Mout, b.Ho * b.Wo, idn, sums_of(next_bn), 0, params, running, ctx,
+                   st));
     cur = ctx + b.out;
   }
   // bn2 -> flatten -> fc -> features -> normalise (resnet_arcface.py:147-151)
   const Block& last = n->blocks.back();
   const int HWl = last.Ho * last.Wo;
-  RUN(bn_forward(n, n->bn_last, cur, ctx + n->off_flat, (int64_t)B * HWl, HWl, nullptr, 1, params, running, ctx, st));
+  RUN(bn_forward(n->bn_last, cur, ctx + n->off_flat, (int64_t)B * HWl, HWl, nullptr, nullptr, 1, params, running, ctx,
+                 st));
   const int Kfc = n->fc.d.Cin;
   int splitk = (Kfc / 32) / 12;
   if (splitk < 1) splitk = 1;
   if (splitk > 64) splitk = 64;
-  RUN(vlsfr_conv2d_fwd(&n->fc.d, ctx + n->off_flat, wc + n->fc.off_wb, ctx + n->off_fcout, splitk, 1, st));
+  RUN(vlsfr_conv2d_fwd(&n->fc.d, ctx + n->off_flat, wc + n->fc.off_wb, ctx + n->off_fcout, splitk, 1, nullptr, st));
   float* rm = running ? running[2 * n->run_feat] : nullptr;
   float* rv = running ? running[2 * n->run_feat + 1] : nullptr;
   RUN(vlsfr_embed_fwd((const float*)(ctx + n->off_fcout), params[n->p_fc_b], params[n->p_feat_w], params[n->p_feat_b],
@@ -361,6 +388,8 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
   const int B = n->B, S = n->HW0;
   const Block& last = n->blocks.back();
   const int HWl = last.Ho * last.Wo;
+  hipError_t e0 = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, (hipStream_t)st);
+  if (e0 != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e0));
   // embedding tail, fc
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd),
@@ -370,7 +399,7 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
   RUN(vlsfr_conv2d_dgrad(&n->fc.d, sc.dfc, wc + n->fc.off_wT, dflat, st));
   char* dcur = sc.g[1];
   RUN(bn_backward(n->bn_last, dflat, ctx + last.out, dcur, (int64_t)B * HWl, HWl, nullptr, 1, params, grads, ctx,
-                  sc.red, st));
+                  st));
   // blocks in reverse; dcur rotates through the three gradient buffers
   int cur_i = 1;
   for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
@@ -381,27 +410,27 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
     char* t2 = sc.g[(cur_i + 2) % 3];
     const char* dout = sc.g[cur_i];
     // main branch
-    RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, sc.red, st));
+    RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
     RUN(vlsfr_conv2d_wgrad(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
-    RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, sc.red, st));   // d c1
+    RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st));   // d c1
     RUN(vlsfr_conv2d_wgrad(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, st));                 // d a1 (in t2)
     const char* add = dout;
     if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
-      RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, sc.red, st));
+      RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
       RUN(vlsfr_conv2d_wgrad(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, st));
       RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
       add = sc.idn;
     }
     // d x_in = bn1 backward of d a1, plus the shortcut gradient
-    RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, sc.red, st));
+    RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st));
     cur_i = (cur_i + 1) % 3;   // t1 is the new dcur
   }
   // stem
   char* dc0 = sc.g[(cur_i + 1) % 3];
   RUN(bn_backward(n->stem_bn, sc.g[cur_i], ctx + n->off_c0, dc0, (int64_t)B * S * S, S * S, nullptr, 0, params, grads,
-                  ctx, sc.red, st));
+                  ctx, st));
   hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e));
   RUN(vlsfr_conv2d_wgrad(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, st));

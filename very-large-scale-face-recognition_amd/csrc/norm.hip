@@ -32,249 +32,331 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-channel sum and sum of squares over the M rows of x[M, C]
-// sums: fp32 [2, C], pre-zeroed, accumulated atomically
+// Streaming skeleton shared by the BatchNorm kernels.  A thread owns ONE 16-byte channel group
+// (8 channels) for the whole kernel, so per-channel constants sit in registers; a block covers a
+// contiguous run of rows (~32 KB of x) with several independent 16-byte loads in flight per thread.
+// Reductions: registers -> wave shuffle over the lanes that share a channel group -> LDS ->
+// one of VLSFR_REPL replicated fp32 accumulators in global memory (replication keeps the
+// same-address atomic contention of thousands of blocks off one cache line; a finalize kernel sums
+// the replicas).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, int C, float* sums) {
-  extern __shared__ float sh[];   // [2, C]
-  const int cg = C / 8;           // 16-byte chunk columns
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 2 * C; i += 256) sh[i] = 0.f;
-  __syncthreads();
-  const int col = tid % cg;
-  const int rsub = tid / cg;
-  const int rows_per_iter = 256 / cg;
-  float s[8], q[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-  if (rsub < rows_per_iter) {
-    for (int64_t r = (int64_t)blockIdx.x * rows_per_iter + rsub; r < M; r += (int64_t)gridDim.x * rows_per_iter) {
-      bf8 v;
-      v.raw = *(const uint4*)(x + r * C + col * 8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float f = v.get(j);
-        s[j] += f;
-        q[j] += f * f;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sh[col * 8 + j], s[j]);
-      atomicAdd(&sh[C + col * 8 + j], q[j]);
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[i], sh[i]);
+constexpr int REPL = VLSFR_BN_REPL;
+
+struct RowMap {
+  int cg, col, rl, rpb;
+  bool active;
+};
+__device__ __forceinline__ RowMap row_map(int C) {
+  RowMap m;
+  m.cg = C / 8;
+  m.rpb = 256 / m.cg;
+  m.col = threadIdx.x % m.cg;
+  m.rl = threadIdx.x / m.cg;
+  m.active = m.rl < m.rpb;
+  return m;
 }
 
-// ---------------------------------------------------------------------------------------------
-// y = prelu(bn(x)) + residual   (each stage optional).  Every block derives scale/shift from the
-// raw sums; block 0 also records mean / invstd and updates the running statistics.
-// ---------------------------------------------------------------------------------------------
+// sums over the block of per-thread partials v[NV][8] into out[rep][NV][C]
+template <int NV>
+__device__ __forceinline__ void block_reduce_to_replica(float (&v)[NV][8], const RowMap& m, int C, float* sh,
+                                                        float* out) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < NV * C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  const bool pow2 = (m.cg & (m.cg - 1)) == 0;
+  if (pow2 && m.cg <= 32) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = m.active ? v[n][j] : 0.f;
+        for (int o = 32; o >= m.cg; o >>= 1) t += __shfl_xor(t, o, 64);
+        v[n][j] = t;
+      }
+    if ((tid & 63) < m.cg) {
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&sh[n * C + m.col * 8 + j], v[n][j]);
+    }
+  } else if (m.active) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&sh[n * C + m.col * 8 + j], v[n][j]);
+  }
+  __syncthreads();
+  float* dst = out + (size_t)(blockIdx.x % REPL) * NV * C;
+  for (int i = tid; i < NV * C; i += 256) atomicAdd(&dst[i], sh[i]);
+}
+
+__device__ __forceinline__ int rows_per_block(int C, int rpb) {
+  int rb = 32768 / (C * 2);
+  if (rb < rpb) rb = rpb;
+  return (rb / rpb) * rpb;
+}
+
+// ---- statistics of x[M, C]: sums[REPL][2][C] (sum, sum of squares), pre-zeroed
+__global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, int C, int RB, float* sums) {
+  extern __shared__ float sh[];
+  const RowMap m = row_map(C);
+  float v[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[0][j] = v[1][j] = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int64_t r1 = r0 + RB < M ? r0 + RB : M;
+  if (m.active) {
+    for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
+      bf8 xv;
+      xv.raw = *(const uint4*)(x + r * C + m.col * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = xv.get(j);
+        v[0][j] += f;
+        v[1][j] += f * f;
+      }
+    }
+  }
+  block_reduce_to_replica<2>(v, m, C, sh, sums);
+}
+
+// ---- replicas -> mean / invstd / scale / shift (+ running statistics)
+struct BnFinArgs {
+  const float* sums;   // [REPL][2][C]
+  int64_t M;
+  int C;
+  const float* gamma;
+  const float* beta;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+  float* running_mean;
+  float* running_var;
+  float eps, momentum;
+};
+__global__ void bn_finalize_kernel(BnFinArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  float s = 0.f, q = 0.f;
+  for (int r = 0; r < REPL; ++r) {
+    s += a.sums[(size_t)r * 2 * a.C + c];
+    q += a.sums[(size_t)r * 2 * a.C + a.C + c];
+  }
+  const float invM = 1.f / (float)a.M;
+  const float mean = s * invM;
+  float var = q * invM - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float invstd = rsqrtf(var + a.eps);
+  const float g = a.gamma ? a.gamma[c] : 1.f;
+  const float b = a.beta ? a.beta[c] : 0.f;
+  a.mean[c] = mean;
+  a.invstd[c] = invstd;
+  a.scale[c] = g * invstd;
+  a.shift[c] = b - mean * g * invstd;
+  if (a.running_mean) {
+    const float unb = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+  }
+}
+
+// ---- y = prelu(x * scale + shift) + residual; optionally the statistics of y for the next BatchNorm
 struct BnApplyArgs {
   const u16* x;
   u16* y;
   int64_t M;
-  int C, HW;
-  const float* sums;      // [2, C]
-  const float* gamma;
-  const float* beta;
+  int C, HW, RB;
+  const float* scale;
+  const float* shift;
   const float* slope;     // PReLU or nullptr
   const u16* residual;    // or nullptr
-  float* save_mean;       // [C]
-  float* save_invstd;     // [C]
-  float* running_mean;    // or nullptr
-  float* running_var;
-  float eps, momentum;
+  float* out_sums;        // [REPL][2][C] statistics of y (pre-zeroed) or nullptr
   int out_nchw;           // 1: y index = n*(C*HW) + c*HW + hw (the flatten order of the reference's fc input)
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
-  extern __shared__ float sh[];   // scale[C], shift[C], slope[C]
-  float* scale = sh;
-  float* shift = sh + a.C;
-  float* slp = sh + 2 * a.C;
-  const int tid = threadIdx.x;
-  const float invM = 1.f / (float)a.M;
-  for (int c = tid; c < a.C; c += 256) {
-    const float mean = a.sums[c] * invM;
-    float var = a.sums[a.C + c] * invM - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    const float invstd = rsqrtf(var + a.eps);
-    const float g = a.gamma ? a.gamma[c] : 1.f;
-    const float b = a.beta ? a.beta[c] : 0.f;
-    scale[c] = g * invstd;
-    shift[c] = b - mean * g * invstd;
-    slp[c] = a.slope ? a.slope[c] : 1.f;
-    if (blockIdx.x == 0) {
-      a.save_mean[c] = mean;
-      a.save_invstd[c] = invstd;
-      if (a.running_mean) {
-        const float unb = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
-        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+  extern __shared__ float sh[];
+  const int C = a.C;
+  const RowMap m = row_map(C);
+  float sc[8], sf[8], sl[8], v[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = m.col * 8 + j;
+    sc[j] = a.scale[c];
+    sf[j] = a.shift[c];
+    sl[j] = a.slope ? a.slope[c] : 1.f;
+    v[0][j] = v[1][j] = 0.f;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * a.RB;
+  const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
+  if (m.active) {
+    for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
+      bf8 xv, rs;
+      xv.raw = *(const uint4*)(a.x + r * C + m.col * 8);
+      if (a.residual) rs.raw = *(const uint4*)(a.residual + r * C + m.col * 8);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = xv.get(j) * sc[j] + sf[j];
+        if (a.slope) z = z > 0.f ? z : z * sl[j];
+        if (a.residual) z += rs.get(j);
+        o[j] = z;
+      }
+      const uint4 packed = pack8(o);
+      if (!a.out_nchw) {
+        *(uint4*)(a.y + r * C + m.col * 8) = packed;
+      } else {
+        const int64_t n = r / a.HW;
+        const int hw = (int)(r - n * a.HW);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a.y[(n * C + m.col * 8 + j) * a.HW + hw] = f2bf(o[j]);
+      }
+      if (a.out_sums) {
+        bf8 yv;
+        yv.raw = packed;   // statistics of what the next layer will actually read
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = yv.get(j);
+          v[0][j] += f;
+          v[1][j] += f * f;
+        }
       }
     }
   }
-  __syncthreads();
-  const int cg = a.C / 8;
-  const int64_t total = a.M * cg;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / cg;
-    const int col = (int)(i - r * cg);
-    bf8 v, rs;
-    v.raw = *(const uint4*)(a.x + r * a.C + col * 8);
-    if (a.residual) rs.raw = *(const uint4*)(a.residual + r * a.C + col * 8);
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = col * 8 + j;
-      float z = v.get(j) * scale[c] + shift[c];
-      if (a.slope) z = z > 0.f ? z : z * slp[c];
-      if (a.residual) z += rs.get(j);
-      o[j] = z;
-    }
-    if (!a.out_nchw) {
-      *(uint4*)(a.y + r * a.C + col * 8) = pack8(o);
-    } else {
-      const int64_t n = r / a.HW;
-      const int hw = (int)(r - n * a.HW);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a.y[(n * a.C + col * 8 + j) * a.HW + hw] = f2bf(o[j]);
-    }
-  }
+  if (a.out_sums) block_reduce_to_replica<2>(v, m, C, sh, a.out_sums);
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward, pass 1: per-channel sum dz, sum dz*xhat, sum dy*min(z,0) (PReLU slope gradient)
-// where z = bn(x), dz = dy * prelu'(z).   red: fp32 [3, C] pre-zeroed.
+// backward: red[REPL][3][C] = sum dz, sum dz*xhat, sum dy*min(z,0) (PReLU slope gradient) with
+// z = bn(x), dz = dy * prelu'(z); then k0 = gamma*invstd, k1 = mean dz, k2 = mean dz*xhat and
+// dx = k0 * (dz - k1 - xhat*k2) (+ dx_add)
 // ---------------------------------------------------------------------------------------------
 struct BnBwdArgs {
   const u16* dy;
   const u16* x;           // BN input (conv output)
   u16* dx;
   int64_t M;
-  int C, HW;
+  int C, HW, RB;
   const float* mean;
   const float* invstd;
   const float* gamma;
   const float* beta;
   const float* slope;     // or nullptr
-  float* red;             // [3, C]
+  float* red;             // [REPL][3][C] pre-zeroed
+  float* kcoef;           // [3][C] written by the finalize kernel
   const u16* dx_add;      // extra gradient added to dx (identity branch) or nullptr
-  float* dgamma;          // accumulated (+=) by block 0 of the apply pass; may be nullptr (frozen)
+  float* dgamma;          // accumulated (+=); may be nullptr (frozen)
   float* dbeta;
   float* dslope;
   int dy_nchw;            // dy laid out as the flatten order (see bn_apply out_nchw)
 };
 
-__device__ __forceinline__ float load_dy(const BnBwdArgs& a, int64_t r, int c) {
-  if (!a.dy_nchw) return bf2f(a.dy[r * a.C + c]);
+__device__ __forceinline__ float load_dy_nchw(const BnBwdArgs& a, int64_t r, int c) {
   const int64_t n = r / a.HW;
   const int hw = (int)(r - n * a.HW);
   return bf2f(a.dy[(n * a.C + c) * a.HW + hw]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
-  extern __shared__ float sh[];   // [3, C]
+  extern __shared__ float sh[];
   const int C = a.C;
-  const int cg = C / 8;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 3 * C; i += 256) sh[i] = 0.f;
-  __syncthreads();
-  const int col = tid % cg;
-  const int rsub = tid / cg;
-  const int rows_per_iter = 256 / cg;
-  float s0[8], s1[8], s2[8], mu[8], is[8], g[8], b[8], sl[8];
+  const RowMap m = row_map(C);
+  float v[3][8], mu[8], is[8], g[8], b[8], sl[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = col * 8 + j;
-    s0[j] = s1[j] = s2[j] = 0.f;
+    const int c = m.col * 8 + j;
+    v[0][j] = v[1][j] = v[2][j] = 0.f;
     mu[j] = a.mean[c];
     is[j] = a.invstd[c];
     g[j] = a.gamma ? a.gamma[c] : 1.f;
     b[j] = a.beta ? a.beta[c] : 0.f;
     sl[j] = a.slope ? a.slope[c] : 1.f;
   }
-  if (rsub < rows_per_iter) {
-    for (int64_t r = (int64_t)blockIdx.x * rows_per_iter + rsub; r < a.M; r += (int64_t)gridDim.x * rows_per_iter) {
+  const int64_t r0 = (int64_t)blockIdx.x * a.RB;
+  const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
+  if (m.active) {
+    for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
       bf8 xv, dv;
-      xv.raw = *(const uint4*)(a.x + r * C + col * 8);
-      if (!a.dy_nchw) dv.raw = *(const uint4*)(a.dy + r * C + col * 8);
+      xv.raw = *(const uint4*)(a.x + r * C + m.col * 8);
+      if (!a.dy_nchw) dv.raw = *(const uint4*)(a.dy + r * C + m.col * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xhat = (xv.get(j) - mu[j]) * is[j];
-        float dyv = a.dy_nchw ? load_dy(a, r, col * 8 + j) : dv.get(j);
+        const float dyv = a.dy_nchw ? load_dy_nchw(a, r, m.col * 8 + j) : dv.get(j);
         float dz = dyv;
         if (a.slope) {
           const float z = xhat * g[j] + b[j];
           if (z <= 0.f) {
-            s2[j] += dyv * z;
+            v[2][j] += dyv * z;
             dz = dyv * sl[j];
           }
         }
-        s0[j] += dz;
-        s1[j] += dz * xhat;
+        v[0][j] += dz;
+        v[1][j] += dz * xhat;
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sh[col * 8 + j], s0[j]);
-      atomicAdd(&sh[C + col * 8 + j], s1[j]);
-      if (a.slope) atomicAdd(&sh[2 * C + col * 8 + j], s2[j]);
-    }
   }
-  __syncthreads();
-  const int nred = a.slope ? 3 * C : 2 * C;
-  for (int i = tid; i < nred; i += 256) atomicAdd(&a.red[i], sh[i]);
+  block_reduce_to_replica<3>(v, m, C, sh, a.red);
 }
 
-// backward, pass 2: dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)) (+ dx_add)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
-  extern __shared__ float sh[];   // k0[C] = gamma*invstd, k1[C] = mean dz, k2[C] = mean dz*xhat
-  const int C = a.C;
-  float* k0 = sh;
-  float* k1 = sh + C;
-  float* k2 = sh + 2 * C;
-  const int tid = threadIdx.x;
-  const float invM = 1.f / (float)a.M;
-  for (int c = tid; c < C; c += 256) {
-    const float g = a.gamma ? a.gamma[c] : 1.f;
-    k0[c] = g * a.invstd[c];
-    k1[c] = a.red[c] * invM;
-    k2[c] = a.red[C + c] * invM;
-    if (blockIdx.x == 0) {
-      if (a.dbeta) a.dbeta[c] += a.red[c];
-      if (a.dgamma) a.dgamma[c] += a.red[C + c];
-      if (a.dslope && a.slope) a.dslope[c] += a.red[2 * C + c];
-    }
+__global__ void bn_bwd_finalize_kernel(BnBwdArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int r = 0; r < REPL; ++r) {
+    const float* p = a.red + (size_t)r * 3 * a.C;
+    s0 += p[c];
+    s1 += p[a.C + c];
+    s2 += p[2 * a.C + c];
   }
-  __syncthreads();
-  const int cg = C / 8;
-  const int64_t total = a.M * cg;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / cg;
-    const int col = (int)(i - r * cg);
+  const float invM = 1.f / (float)a.M;
+  a.kcoef[c] = (a.gamma ? a.gamma[c] : 1.f) * a.invstd[c];
+  a.kcoef[a.C + c] = s0 * invM;
+  a.kcoef[2 * a.C + c] = s1 * invM;
+  if (a.dbeta) a.dbeta[c] += s0;
+  if (a.dgamma) a.dgamma[c] += s1;
+  if (a.dslope && a.slope) a.dslope[c] += s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  const int C = a.C;
+  const RowMap m = row_map(C);
+  if (!m.active) return;
+  float k0[8], k1[8], k2[8], mu[8], is[8], g[8], b[8], sl[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = m.col * 8 + j;
+    k0[j] = a.kcoef[c];
+    k1[j] = a.kcoef[C + c];
+    k2[j] = a.kcoef[2 * C + c];
+    mu[j] = a.mean[c];
+    is[j] = a.invstd[c];
+    g[j] = a.gamma ? a.gamma[c] : 1.f;
+    b[j] = a.beta ? a.beta[c] : 0.f;
+    sl[j] = a.slope ? a.slope[c] : 1.f;
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * a.RB;
+  const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
+  for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
     bf8 xv, dv, av;
-    xv.raw = *(const uint4*)(a.x + r * C + col * 8);
-    if (!a.dy_nchw) dv.raw = *(const uint4*)(a.dy + r * C + col * 8);
-    if (a.dx_add) av.raw = *(const uint4*)(a.dx_add + r * C + col * 8);
+    xv.raw = *(const uint4*)(a.x + r * C + m.col * 8);
+    if (!a.dy_nchw) dv.raw = *(const uint4*)(a.dy + r * C + m.col * 8);
+    if (a.dx_add) av.raw = *(const uint4*)(a.dx_add + r * C + m.col * 8);
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = col * 8 + j;
-      const float xhat = (xv.get(j) - a.mean[c]) * a.invstd[c];
-      float dz = a.dy_nchw ? load_dy(a, r, c) : dv.get(j);
+      const float xhat = (xv.get(j) - mu[j]) * is[j];
+      float dz = a.dy_nchw ? load_dy_nchw(a, r, m.col * 8 + j) : dv.get(j);
       if (a.slope) {
-        const float z = xhat * (a.gamma ? a.gamma[c] : 1.f) + (a.beta ? a.beta[c] : 0.f);
-        if (z <= 0.f) dz *= a.slope[c];
+        const float z = xhat * g[j] + b[j];
+        if (z <= 0.f) dz *= sl[j];
       }
-      float d = k0[c] * (dz - k1[c] - xhat * k2[c]);
+      float d = k0[j] * (dz - k1[j] - xhat * k2[j]);
       if (a.dx_add) d += av.get(j);
       o[j] = d;
     }
-    *(uint4*)(a.dx + r * C + col * 8) = pack8(o);
+    *(uint4*)(a.dx + r * C + m.col * 8) = pack8(o);
   }
 }
 
@@ -477,25 +559,48 @@ inline int blocks_for(int64_t work_items, int per_block = 256, int cap = 2048) {
 
 extern "C" {
 
+static int bn_geom(int64_t M, int C, int* RB, int* nblk) {
+  const int cg = C / 8;
+  const int rpb = 256 / cg;
+  if (rpb < 1) return -1;
+  int rb = 32768 / (C * 2);
+  if (rb < rpb) rb = rpb;
+  rb = (rb / rpb) * rpb;
+  *RB = rb;
+  *nblk = (int)((M + rb - 1) / rb);
+  return 0;
+}
+
 int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream) {
   if (!x || !sums || M <= 0 || C <= 0 || C % 8 || C > 2048)
     return fail(VLSFR_EINVAL, "vlsfr_bn_stats: need C %% 8 == 0, C <= 2048 (got %d)", C);
-  const int rows_per_iter = 256 / (C / 8);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks_for(M, rows_per_iter * 8, 1024)), dim3(256), 2 * C * sizeof(float),
-                     (hipStream_t)stream, (const u16*)x, M, C, sums);
+  int RB, nblk;
+  bn_geom(M, C, &RB, &nblk);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                     (const u16*)x, M, C, RB, sums);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_stats");
   return VLSFR_OK;
 }
 
-int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums, const float* gamma,
-                   const float* beta, const float* slope, const void* residual, float* save_mean,
-                   float* save_invstd, float* running_mean, float* running_var, float eps, float momentum,
-                   int32_t out_nchw, void* stream) {
-  if (!x || !y || !sums || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
+int vlsfr_bn_finalize(const float* sums, int64_t M, int32_t C, const float* gamma, const float* beta, float* mean,
+                      float* invstd, float* scale, float* shift, float* running_mean, float* running_var, float eps,
+                      float momentum, void* stream) {
+  if (!sums || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0)
+    return fail(VLSFR_EINVAL, "vlsfr_bn_finalize: bad argument");
+  BnFinArgs a{sums, M, C, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, eps, momentum};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_finalize");
+  return VLSFR_OK;
+}
+
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* scale, const float* shift,
+                   const float* slope, const void* residual, float* out_sums, int32_t out_nchw, void* stream) {
+  if (!x || !y || !scale || !shift || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_apply: bad argument");
-  BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, sums, gamma, beta, slope, (const u16*)residual, save_mean,
-                save_invstd, running_mean, running_var, eps, momentum, out_nchw};
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks_for(M * (C / 8), 256 * 4)), dim3(256), 3 * C * sizeof(float),
+  int RB, nblk;
+  bn_geom(M, C, &RB, &nblk);
+  BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, scale, shift, slope, (const u16*)residual, out_sums, out_nchw};
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(256), out_sums ? 2 * C * sizeof(float) : 0,
                      (hipStream_t)stream, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_apply");
   return VLSFR_OK;
@@ -503,20 +608,20 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
 
 int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
-                      const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw, void* stream) {
-  if (!dy || !x || !dx || !mean || !invstd || !red || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
+                      float* kcoef, const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw,
+                      void* stream) {
+  if (!dy || !x || !dx || !mean || !invstd || !red || !kcoef || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_backward: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(red, 0, 3 * C * sizeof(float), st);
-  if (e != hipSuccess) return hip_fail(e, "vlsfr_bn_backward: memset");
-  BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, mean, invstd, gamma, beta, slope, red,
+  int RB, nblk;
+  bn_geom(M, C, &RB, &nblk);
+  BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red, kcoef,
               (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw};
-  const int rows_per_iter = 256 / (C / 8);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks_for(M, rows_per_iter * 8, 1024)), dim3(256),
-                     3 * C * sizeof(float), st, a);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 3 * C * sizeof(float), st, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward reduce");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks_for(M * (C / 8), 256 * 4)), dim3(256), 3 * C * sizeof(float), st,
-                     a);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward finalize");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward apply");
   return VLSFR_OK;
 }
