@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--feat", type=int, default=512)
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the "
+                    "multi-process path on a 1-GPU box")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -118,13 +120,17 @@ def main():
                              "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     import vlsfr_amd  # noqa: F401
     from vlsfr_amd import _lib
@@ -152,7 +158,7 @@ def main():
         loss = step_model(x, y, xl, yl)
         loss.backward()
         if world > 1:
-            step_model.reduce_gradients()
+            step_model.reduce_gradients(opt)
         opt.step()
         return loss
 

@@ -192,26 +192,24 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
 /* Per-channel reductions are kept in VLSFR_BN_REPL replicated accumulators (fp32
  * [VLSFR_BN_REPL][n][C], pre-zeroed by the caller, accumulated atomically) and folded by the
  * finalize step. */
-#define VLSFR_BN_REPL 32
+#define VLSFR_BN_REPL 8
 /* sums [REPL][2][C]: sum and sum of squares over the M rows of x */
 int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream);
-/* sums -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale (fp32 [C] each), and the
- * running statistics update (momentum, unbiased variance) when running_* are given */
-int vlsfr_bn_finalize(const float* sums, int64_t M, int32_t C, const float* gamma, const float* beta,
-                      float* mean, float* invstd, float* scale, float* shift, float* running_mean,
-                      float* running_var, float eps, float momentum, void* stream);
-/* y = prelu(x*scale + shift) + residual; slope / residual may be NULL; out_sums (optional): the
- * statistics [REPL][2][C] of y for the next BatchNorm; out_nchw writes y in the [n][c][hw] flatten
- * order of the reference's fc input (HW = rows per image) */
-int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* scale,
-                   const float* shift, const float* slope, const void* residual, float* out_sums,
-                   int32_t out_nchw, void* stream);
+/* y = prelu(bn(x)) + residual from the statistics `sums` of x (every block folds the replicas into
+ * scale / shift itself; mean, invstd are saved for the backward pass; running_* get the momentum
+ * update with the unbiased variance).  slope / residual / running_* may be NULL.  out_sums
+ * (optional): the statistics [REPL][2][C] of y, for the next BatchNorm.  out_nchw writes y in the
+ * [n][c][hw] flatten order of the reference's fc input (HW = rows per image). */
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums,
+                   const float* gamma, const float* beta, const float* slope, const void* residual,
+                   float* save_mean, float* save_invstd, float* running_mean, float* running_var,
+                   float eps, float momentum, float* out_sums, int32_t out_nchw, void* stream);
 /* dx = d(prelu(bn(x)))/dx applied to dy (+ dx_add); dgamma/dbeta/dslope are accumulated (+=);
- * red: fp32 [REPL][3][C] pre-zeroed scratch; kcoef: fp32 [3][C] scratch */
+ * red: fp32 [REPL][3][C] pre-zeroed scratch */
 int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
-                      const float* slope, float* red, float* kcoef, const void* dx_add, float* dgamma,
-                      float* dbeta, float* dslope, int32_t dy_nchw, void* stream);
+                      const float* slope, float* red, const void* dx_add, float* dgamma, float* dbeta,
+                      float* dslope, int32_t dy_nchw, void* stream);
 int vlsfr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* e = normalize(bn1d(fc + fc_bias)); all fp32 [B, D] */
 int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, const float* beta,

@@ -167,3 +167,36 @@ def test_head_dense_torch_reference_1m():
     np.testing.assert_allclose(float(loss), float(tot), rtol=2e-3)
     np.testing.assert_allclose(p.grad.cpu().numpy(), pr.grad.cpu().numpy(), rtol=5e-2,
                                atol=4e-3 * float(pr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("loss_type,margin", [("Arc", 0.5), ("SV", 0.35)])
+def test_head_row_sharded_equals_full_batch(loss_type, margin):
+    """Data-parallel semantics (parallel.py): two simulated ranks, each with its own replica of the
+    pool and allocator, each holding half of the probe rows but seeing the whole batch's gallery
+    embeddings and labels.  Sum of the rank losses == single-process loss on the concatenated batch,
+    dL/dp rows match, and both replicas end in the single-process pool / LRU / queue_position state."""
+    Q, D, B, T, n_id = 4000, 128, 48, 3, 5000
+    case = common.head_case(4242, Q, D, B, T, n_id)
+    full = make_head(case["queue0"], loss_type, 32.0, margin, True)
+    ranks = [make_head(case["queue0"], loss_type, 32.0, margin, True) for _ in range(2)]
+    h = B // 2
+    for t in range(T):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            g = torch.from_numpy(case["G"][t, s]).cuda()
+            p = torch.from_numpy(case["P"][t, s]).cuda().requires_grad_(True)
+            loss = full.run_pass(p, g, pl, gl, trans)
+            loss.backward()
+            tot, grads = 0.0, []
+            for r, head in enumerate(ranks):
+                pr = torch.from_numpy(case["P"][t, s][r * h:(r + 1) * h]).cuda().requires_grad_(True)
+                lr = head.run_pass(pr, g, pl, gl, trans, row_offset=r * h)
+                lr.backward()
+                tot += float(lr.detach())
+                grads.append(pr.grad)
+            np.testing.assert_allclose(tot, float(loss.detach()), rtol=1e-5)
+            np.testing.assert_allclose(torch.cat(grads).cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    for head in ranks:
+        assert head.lru.state_dict() == full.lru.state_dict()
+        assert head.qp.tolist() == full.qp.tolist()
+        assert torch.equal(head.queue, full.queue)

@@ -70,22 +70,29 @@ struct ConvArgs {
   float* stats;      // optional [VLSFR_BN_REPL][2][Mrows] BatchNorm statistics of the rounded output
 };
 
-__device__ __forceinline__ int swz4(int row) {
-  // chunk swizzle for 64-byte LDS rows read with ds_read_b128 by (row = lane & 15, chunk = lane >> 4):
-  // XOR the 16-byte chunk index with g[(row >> 2) & 3], g = {0, 2, 3, 1} — conflict-free for every
-  // 16-lane service group of the instruction.
-  return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+// LDS image of a k-tile: [rows][BK] bf16, the 16-byte chunks of a row XOR-swizzled with the row so
+// that the ds_read_b128 fragment reads (row = lane & 15, chunk = 4 kk + (lane >> 4)) are
+// bank-conflict free for every 16-lane service group of the instruction:
+//   BK = 32 (64-byte rows):  chunk ^ g[(row >> 2) & 3], g = {0, 2, 3, 1}
+//   BK = 64 (128-byte rows): chunk ^ (row & 7)
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  if constexpr (BK == 32) return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+  else return row & 7;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int MT = BM / 32;   // 16-row MFMA tiles per wave along output channels
   constexpr int NT = BN / 32;   // along pixels
-  constexpr int ACH = BM * 4 / 256;   // 16-byte chunks per thread, weight tile
-  constexpr int BCH = BN * 4 / 256;   // pixel tile
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 64];
+  constexpr int CPR = BK / 8;   // 16-byte chunks per row
+  constexpr int RPP = 256 / CPR;            // rows staged per pass of the 256 threads
+  constexpr int ACH = BM / RPP;             // chunks per thread, weight tile
+  constexpr int BCH = BN / RPP;             // pixel tile
+  constexpr int RSB = BK * 2;               // LDS row bytes
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * RSB];
   char* sA = smem;
-  char* sB = smem + 2 * BM * 64;
+  char* sB = smem + 2 * BM * RSB;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int K = a.R * a.S * a.C;
   const int m0 = blockIdx.y * BM;
   const int p0 = blockIdx.x * BN;
-  const int nkt = K / 32;
+  const int nkt = K / BK;
   // split-K range of k-tiles
   const int per = (nkt + a.splitk - 1) / a.splitk;
   const int kt0 = blockIdx.z * per;
@@ -103,12 +110,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   if (kt0 >= kt1) return;
 
   // ---- per-thread staging coordinates
+  const int srow = tid / CPR;
+  const int chunk = tid % CPR;
   int b_n[BCH], b_h[BCH], b_w[BCH];
   bool b_ok[BCH];
 #pragma unroll
   for (int u = 0; u < BCH; ++u) {
-    const int prow = (tid >> 2) + 64 * u;
-    const int p = p0 + prow;
+    const int p = p0 + srow + RPP * u;
     b_ok[u] = p < P;
     const int pp = b_ok[u] ? p : 0;
     const int n = pp / (a.Ho * a.Wo);
@@ -124,19 +132,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       b_w[u] = wo + a.pad;
     }
   }
-  const int chunk = tid & 3;
   uint4 ra[ACH], rb[BCH];
 
   auto issue = [&](int kt) {
-    const int k0 = kt * 32;
+    const int k0 = kt * BK;
     const int tap = k0 / a.C;
     const int c0 = k0 - tap * a.C;
     const int r = tap / a.S;
     const int s = tap - r * a.S;
 #pragma unroll
     for (int u = 0; u < ACH; ++u) {
-      const int row = (tid >> 2) + 64 * u;
-      const int m = m0 + row;
+      const int m = m0 + srow + RPP * u;
       if (m < a.Mrows) ra[u] = *(const uint4*)(a.w + (size_t)m * K + k0 + chunk * 8);
       else ra[u] = make_uint4(0, 0, 0, 0);
     }
@@ -166,13 +172,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   auto stage = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < ACH; ++u) {
-      const int row = (tid >> 2) + 64 * u;
-      *(uint4*)(sA + buf * BM * 64 + row * 64 + ((chunk ^ swz4(row)) << 4)) = ra[u];
+      const int row = srow + RPP * u;
+      *(uint4*)(sA + buf * BM * RSB + row * RSB + ((chunk ^ swz<BK>(row)) << 4)) = ra[u];
     }
 #pragma unroll
     for (int u = 0; u < BCH; ++u) {
-      const int row = (tid >> 2) + 64 * u;
-      *(uint4*)(sB + buf * BN * 64 + row * 64 + ((chunk ^ swz4(row)) << 4)) = rb[u];
+      const int row = srow + RPP * u;
+      *(uint4*)(sB + buf * BN * RSB + row * RSB + ((chunk ^ swz<BK>(row)) << 4)) = rb[u];
     }
   };
 
@@ -185,21 +191,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   issue(kt0);
   stage(0);
   __syncthreads();
-  const int rd_off = r16 * 64 + ((h ^ swz4(r16)) << 4);
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < kt1) issue(kt + 1);
-    bf16x8 fa[MT], fb[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-      fa[i] = *(const bf16x8*)(sA + buf * BM * 64 + (wm * (BM / 2) + i * 16) * 64 + rd_off);
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      const int rd_off = r16 * RSB + (((kk * 4 + h) ^ swz<BK>(r16)) << 4);
+      bf16x8 fa[MT], fb[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-      fb[j] = *(const bf16x8*)(sB + buf * BN * 64 + (wn * (BN / 2) + j * 16) * 64 + rd_off);
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *(const bf16x8*)(sA + buf * BM * RSB + (wm * (BM / 2) + i * 16) * RSB + rd_off);
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int j = 0; j < NT; ++j)
+        fb[j] = *(const bf16x8*)(sB + buf * BN * RSB + (wn * (BN / 2) + j * 16) * RSB + rd_off);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    }
     if (kt + 1 < kt1) stage(buf ^ 1);
     __syncthreads();
   }
@@ -415,7 +424,8 @@ inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - 
 template <int BM, int BN>
 void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN>), grid, dim3(256), 0, st, a);
+  if (a.C % 64 == 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32>), grid, dim3(256), 0, st, a);
 }
 
 int run_igemm(ConvArgs a, hipStream_t st) {

@@ -257,18 +257,16 @@ int bn_forward(const Bn& b, const void* x, void* y, int64_t M, int HW, const voi
                int out_nchw, const float* const* params, float* const* running, char* ctx, void* st) {
   float* rm = running ? running[2 * b.run] : nullptr;
   float* rv = running ? running[2 * b.run + 1] : nullptr;
-  RUN(vlsfr_bn_finalize((const float*)(ctx + b.off_sums), M, b.C, params[b.p_w], params[b.p_b],
-                        (float*)(ctx + b.off_mean), (float*)(ctx + b.off_invstd), (float*)(ctx + b.off_scale),
-                        (float*)(ctx + b.off_shift), rm, rv, BN_EPS, BN_MOM, st));
-  return vlsfr_bn_apply(x, y, M, b.C, HW, (const float*)(ctx + b.off_scale), (const float*)(ctx + b.off_shift),
-                        b.p_slope >= 0 ? params[b.p_slope] : nullptr, residual, out_sums, out_nchw, st);
+  return vlsfr_bn_apply(x, y, M, b.C, HW, (const float*)(ctx + b.off_sums), params[b.p_w], params[b.p_b],
+                        b.p_slope >= 0 ? params[b.p_slope] : nullptr, residual, (float*)(ctx + b.off_mean),
+                        (float*)(ctx + b.off_invstd), rm, rv, BN_EPS, BN_MOM, out_sums, out_nchw, st);
 }
 
 int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M, int HW, const void* dx_add,
                 int dy_nchw, const float* const* params, float* const* grads, char* ctx, void* st) {
   return vlsfr_bn_backward(dy, x, dx, M, b.C, HW, (const float*)(ctx + b.off_mean), (const float*)(ctx + b.off_invstd),
                            params[b.p_w], params[b.p_b], b.p_slope >= 0 ? params[b.p_slope] : nullptr,
-                           (float*)(ctx + b.off_red), (float*)(ctx + b.off_kcoef), dx_add, grads[b.p_w], grads[b.p_b],
+                           (float*)(ctx + b.off_red), dx_add, grads[b.p_w], grads[b.p_b],
                            b.p_slope >= 0 ? grads[b.p_slope] : nullptr, dy_nchw, st);
 }
 

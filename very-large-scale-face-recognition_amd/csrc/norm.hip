@@ -120,74 +120,71 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, 
   block_reduce_to_replica<2>(v, m, C, sh, sums);
 }
 
-// ---- replicas -> mean / invstd / scale / shift (+ running statistics)
-struct BnFinArgs {
-  const float* sums;   // [REPL][2][C]
-  int64_t M;
-  int C;
-  const float* gamma;
-  const float* beta;
-  float* mean;
-  float* invstd;
-  float* scale;
-  float* shift;
-  float* running_mean;
-  float* running_var;
-  float eps, momentum;
-};
-__global__ void bn_finalize_kernel(BnFinArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
-  float s = 0.f, q = 0.f;
-  for (int r = 0; r < REPL; ++r) {
-    s += a.sums[(size_t)r * 2 * a.C + c];
-    q += a.sums[(size_t)r * 2 * a.C + a.C + c];
-  }
-  const float invM = 1.f / (float)a.M;
-  const float mean = s * invM;
-  float var = q * invM - mean * mean;
-  var = var > 0.f ? var : 0.f;
-  const float invstd = rsqrtf(var + a.eps);
-  const float g = a.gamma ? a.gamma[c] : 1.f;
-  const float b = a.beta ? a.beta[c] : 0.f;
-  a.mean[c] = mean;
-  a.invstd[c] = invstd;
-  a.scale[c] = g * invstd;
-  a.shift[c] = b - mean * g * invstd;
-  if (a.running_mean) {
-    const float unb = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
-    a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
-    a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
-  }
-}
-
-// ---- y = prelu(x * scale + shift) + residual; optionally the statistics of y for the next BatchNorm
+// ---- y = prelu(bn(x)) + residual.  Every block folds the replicated statistics into
+// scale = gamma*invstd / shift = beta - mean*scale itself (a few L2-resident loads per thread), so
+// there is no separate finalize launch; block 0 also records mean / invstd and updates the running
+// statistics.  Optionally accumulates the statistics of y for the next BatchNorm.
 struct BnApplyArgs {
   const u16* x;
   u16* y;
   int64_t M;
   int C, HW, RB;
-  const float* scale;
-  const float* shift;
+  const float* sums;      // [REPL][2][C] statistics of x
+  const float* gamma;
+  const float* beta;
   const float* slope;     // PReLU or nullptr
   const u16* residual;    // or nullptr
+  float* save_mean;       // [C]
+  float* save_invstd;     // [C]
+  float* running_mean;    // or nullptr
+  float* running_var;
+  float eps, momentum;
   float* out_sums;        // [REPL][2][C] statistics of y (pre-zeroed) or nullptr
   int out_nchw;           // 1: y index = n*(C*HW) + c*HW + hw (the flatten order of the reference's fc input)
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
-  extern __shared__ float sh[];
+  extern __shared__ float sh[];   // scale[C], shift[C]; reused by the output-statistics reduction
   const int C = a.C;
+  const int tid = threadIdx.x;
+  const float invM = 1.f / (float)a.M;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int r = 0; r < REPL; ++r) {
+      s += a.sums[(size_t)r * 2 * C + c];
+      q += a.sums[(size_t)r * 2 * C + C + c];
+    }
+    const float mean = s * invM;
+    float var = q * invM - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float invstd = rsqrtf(var + a.eps);
+    const float g = a.gamma ? a.gamma[c] : 1.f;
+    const float b = a.beta ? a.beta[c] : 0.f;
+    sh[c] = g * invstd;
+    sh[C + c] = b - mean * g * invstd;
+    if (blockIdx.x == 0) {
+      a.save_mean[c] = mean;
+      a.save_invstd[c] = invstd;
+      if (a.running_mean) {
+        const float unb = a.M > 1 ? var * (float)a.M / (float)(a.M - 1) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unb;
+      }
+    }
+  }
+  __syncthreads();
   const RowMap m = row_map(C);
   float sc[8], sf[8], sl[8], v[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
-    sc[j] = a.scale[c];
-    sf[j] = a.shift[c];
+    sc[j] = sh[c];
+    sf[j] = sh[C + c];
     sl[j] = a.slope ? a.slope[c] : 1.f;
     v[0][j] = v[1][j] = 0.f;
   }
+  __syncthreads();   // sh is reused below
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
   if (m.active) {
@@ -244,7 +241,6 @@ struct BnBwdArgs {
   const float* beta;
   const float* slope;     // or nullptr
   float* red;             // [REPL][3][C] pre-zeroed
-  float* kcoef;           // [3][C] written by the finalize kernel
   const u16* dx_add;      // extra gradient added to dx (identity branch) or nullptr
   float* dgamma;          // accumulated (+=); may be nullptr (frozen)
   float* dbeta;
@@ -300,36 +296,39 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   block_reduce_to_replica<3>(v, m, C, sh, a.red);
 }
 
-__global__ void bn_bwd_finalize_kernel(BnBwdArgs a) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.C) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int r = 0; r < REPL; ++r) {
-    const float* p = a.red + (size_t)r * 3 * a.C;
-    s0 += p[c];
-    s1 += p[a.C + c];
-    s2 += p[2 * a.C + c];
-  }
-  const float invM = 1.f / (float)a.M;
-  a.kcoef[c] = (a.gamma ? a.gamma[c] : 1.f) * a.invstd[c];
-  a.kcoef[a.C + c] = s0 * invM;
-  a.kcoef[2 * a.C + c] = s1 * invM;
-  if (a.dbeta) a.dbeta[c] += s0;
-  if (a.dgamma) a.dgamma[c] += s1;
-  if (a.dslope && a.slope) a.dslope[c] += s2;
-}
-
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  extern __shared__ float sh[];   // k0[C] = gamma*invstd, k1[C] = mean dz, k2[C] = mean dz*xhat
   const int C = a.C;
+  const int tid = threadIdx.x;
+  const float invM = 1.f / (float)a.M;
+  for (int c = tid; c < C; c += 256) {   // fold the replicated reductions (no separate finalize launch)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < REPL; ++r) {
+      const float* p = a.red + (size_t)r * 3 * C;
+      s0 += p[c];
+      s1 += p[C + c];
+      s2 += p[2 * C + c];
+    }
+    sh[c] = (a.gamma ? a.gamma[c] : 1.f) * a.invstd[c];
+    sh[C + c] = s0 * invM;
+    sh[2 * C + c] = s1 * invM;
+    if (blockIdx.x == 0) {
+      if (a.dbeta) a.dbeta[c] += s0;
+      if (a.dgamma) a.dgamma[c] += s1;
+      if (a.dslope && a.slope) a.dslope[c] += s2;
+    }
+  }
+  __syncthreads();
   const RowMap m = row_map(C);
   if (!m.active) return;
   float k0[8], k1[8], k2[8], mu[8], is[8], g[8], b[8], sl[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
-    k0[j] = a.kcoef[c];
-    k1[j] = a.kcoef[C + c];
-    k2[j] = a.kcoef[2 * C + c];
+    k0[j] = sh[c];
+    k1[j] = sh[C + c];
+    k2[j] = sh[2 * C + c];
     mu[j] = a.mean[c];
     is[j] = a.invstd[c];
     g[j] = a.gamma ? a.gamma[c] : 1.f;
@@ -582,46 +581,34 @@ int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* strea
   return VLSFR_OK;
 }
 
-int vlsfr_bn_finalize(const float* sums, int64_t M, int32_t C, const float* gamma, const float* beta, float* mean,
-                      float* invstd, float* scale, float* shift, float* running_mean, float* running_var, float eps,
-                      float momentum, void* stream) {
-  if (!sums || !mean || !invstd || !scale || !shift || M <= 0 || C <= 0)
-    return fail(VLSFR_EINVAL, "vlsfr_bn_finalize: bad argument");
-  BnFinArgs a{sums, M, C, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, eps, momentum};
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
-  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_finalize");
-  return VLSFR_OK;
-}
-
-int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* scale, const float* shift,
-                   const float* slope, const void* residual, float* out_sums, int32_t out_nchw, void* stream) {
-  if (!x || !y || !scale || !shift || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums, const float* gamma,
+                   const float* beta, const float* slope, const void* residual, float* save_mean,
+                   float* save_invstd, float* running_mean, float* running_var, float eps, float momentum,
+                   float* out_sums, int32_t out_nchw, void* stream) {
+  if (!x || !y || !sums || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_apply: bad argument");
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
-  BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, scale, shift, slope, (const u16*)residual, out_sums, out_nchw};
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(256), out_sums ? 2 * C * sizeof(float) : 0,
-                     (hipStream_t)stream, a);
+  BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, sums, gamma, beta, slope, (const u16*)residual, save_mean,
+                save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw};
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_apply");
   return VLSFR_OK;
 }
 
 int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
-                      float* kcoef, const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw,
-                      void* stream) {
-  if (!dy || !x || !dx || !mean || !invstd || !red || !kcoef || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
+                      const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw, void* stream) {
+  if (!dy || !x || !dx || !mean || !invstd || !red || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_backward: bad argument");
   hipStream_t st = (hipStream_t)stream;
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
-  BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red, kcoef,
+  BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
               (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw};
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 3 * C * sizeof(float), st, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward reduce");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a);
-  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward finalize");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk), dim3(256), 3 * C * sizeof(float), st, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward apply");
   return VLSFR_OK;
 }

@@ -94,7 +94,21 @@ class IResNet(nn.Module):
         self._w_sig = None
         self._scratch = None
         self._eval_ctx = None
+        self._nbt_pending = 0
         self.weights_dirty = True
+
+    def flush_counters(self):
+        """Adds the forward passes seen since the last flush to every BatchNorm's num_batches_tracked
+        (kept off the per-step path: the reference bumps ~80 tiny tensors per forward)."""
+        if self._nbt_pending:
+            for name, b in self.named_buffers():
+                if name.endswith("num_batches_tracked"):
+                    b += self._nbt_pending
+            self._nbt_pending = 0
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_counters()
+        return super(IResNet, self).state_dict(*args, **kwargs)
 
     def _make_layer(self, planes, blocks):                     # resnet_arcface.py:112-136 (stride 2, no dilation)
         downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, 2, bias=False),
@@ -188,9 +202,7 @@ class IResNet(nn.Module):
                                            ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_void_p(emb.data_ptr()),
                                            _stream()), "vlsfr_iresnet_forward")
         if self.training:
-            for name, b in self.named_buffers():
-                if name.endswith("num_batches_tracked"):
-                    b += 1
+            self._nbt_pending += 1          # num_batches_tracked is materialised lazily (flush_counters)
         self._keep = x
         return emb, ws
 

@@ -42,7 +42,7 @@ def cast_weight(w_f32, rows, taps, C, Kp=None, transpose=True):
     return wb, wT
 
 
-BN_REPL = 32   # VLSFR_BN_REPL
+BN_REPL = 8   # VLSFR_BN_REPL
 
 
 def conv2d_fwd(x, w, desc, splitk=1, out_f32=False, stats=None):
@@ -79,21 +79,14 @@ def bn_stats(x, M, C):
     return sums
 
 
-def bn_finalize(sums, M, C, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
-    mk = lambda: torch.empty(C, dtype=torch.float32, device=sums.device)
-    mean, invstd, scale, shift = mk(), mk(), mk(), mk()
-    _call("vlsfr_bn_finalize", _p(sums), ctypes.c_int64(M), ctypes.c_int32(C), _p(gamma), _p(beta), _p(mean),
-          _p(invstd), _p(scale), _p(shift), _p(running_mean), _p(running_var), ctypes.c_float(eps),
-          ctypes.c_float(momentum), _st())
-    return mean, invstd, scale, shift
-
-
 def bn_apply(x, M, C, HW, sums, gamma, beta, slope=None, residual=None, running_mean=None, running_var=None,
              out_nchw=False, eps=1e-5, momentum=0.1, out_sums=None):
-    mean, invstd, scale, shift = bn_finalize(sums, M, C, gamma, beta, running_mean, running_var, eps, momentum)
     y = torch.empty(M * C, dtype=torch.bfloat16, device=x.device)
-    _call("vlsfr_bn_apply", _p(x), _p(y), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW), _p(scale),
-          _p(shift), _p(slope), _p(residual), _p(out_sums), ctypes.c_int32(int(out_nchw)), _st())
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    _call("vlsfr_bn_apply", _p(x), _p(y), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW), _p(sums),
+          _p(gamma), _p(beta), _p(slope), _p(residual), _p(mean), _p(invstd), _p(running_mean), _p(running_var),
+          ctypes.c_float(eps), ctypes.c_float(momentum), _p(out_sums), ctypes.c_int32(int(out_nchw)), _st())
     return y, mean, invstd
 
 
@@ -101,9 +94,8 @@ def bn_backward(dy, x, M, C, HW, mean, invstd, gamma, beta, slope=None, dx_add=N
                 dslope=None, dy_nchw=False):
     dx = torch.empty(M * C, dtype=torch.bfloat16, device=x.device)
     red = torch.zeros(BN_REPL, 3, C, dtype=torch.float32, device=x.device)
-    kcoef = torch.empty(3, C, dtype=torch.float32, device=x.device)
     _call("vlsfr_bn_backward", _p(dy), _p(x), _p(dx), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW),
-          _p(mean), _p(invstd), _p(gamma), _p(beta), _p(slope), _p(red), _p(kcoef), _p(dx_add), _p(dgamma), _p(dbeta),
+          _p(mean), _p(invstd), _p(gamma), _p(beta), _p(slope), _p(red), _p(dx_add), _p(dgamma), _p(dbeta),
           _p(dslope), ctypes.c_int32(int(dy_nchw)), _st())
     return dx
 

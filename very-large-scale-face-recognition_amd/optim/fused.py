@@ -74,6 +74,36 @@ class FusedSGD(torch.optim.Optimizer):
         defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, dampening=0.0)
         super(FusedSGD, self).__init__(params, defaults)
         self._caches = {}
+        self._flat_grad = None
+
+    def _attach_flat_grads(self):
+        """One flat fp32 gradient buffer; every p.grad becomes a view of it with p's own (dense)
+        strides, so zero_grad is a single memset and a multi-GPU all-reduce needs no packing."""
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not ps or not ps[0].is_cuda:
+            return None
+        total = sum(p.numel() for p in ps)
+        flat = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            if p.dtype != torch.float32 or not _dense_same_layout([p.data]):
+                return None
+            view = torch.as_strided(flat, p.shape, p.stride(), storage_offset=off)
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view
+            off += p.numel()
+        self._flat_grad = flat
+        self._flat_key = tuple(p.grad.data_ptr() for p in ps)
+        return flat
+
+    def flat_grad(self):
+        """The flat gradient buffer (attached on first use), or None if the layout does not allow it."""
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if self._flat_grad is None or any(p.grad is None for p in ps) or \
+                self._flat_key != tuple(p.grad.data_ptr() for p in ps):
+            return self._attach_flat_grads()
+        return self._flat_grad
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -111,7 +141,12 @@ class FusedSGD(torch.optim.Optimizer):
         """Gradients are accumulated in place by the backbone executor, so keep the buffers and
         clear them (set_to_none=True is honoured but costs a re-allocation on the next backward)."""
         if set_to_none:
+            self._flat_grad = None
             return super(FusedSGD, self).zero_grad(set_to_none=True)
+        flat = self.flat_grad()
+        if flat is not None:
+            flat.zero_()
+            return
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is not None:

@@ -24,10 +24,16 @@ class DataParallelFFC(object):
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.cpu_group = dist.new_group(backend="gloo")
+        self.rccl = dist.get_backend() == "nccl"   # "nccl" IS RCCL on ROCm; gloo only in the 1-GPU rehearsal
         self._flat = None
         # identical starting point on every rank
         for t in list(model.parameters()) + list(model.buffers()):
-            dist.broadcast(t.data, src=0)
+            if self.rccl:
+                dist.broadcast(t.data, src=0)
+            else:
+                c = t.data.cpu()
+                dist.broadcast(c, src=0)
+                t.data.copy_(c)
 
     def _gather_labels(self, lab):
         lab = torch.as_tensor(lab, dtype=torch.int64).cpu().contiguous()
@@ -36,9 +42,13 @@ class DataParallelFFC(object):
         return torch.cat(out).numpy()
 
     def _gather_rows(self, g):
-        out = torch.empty(self.world * g.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
-        self.dist.all_gather_into_tensor(out, g.contiguous())
-        return out
+        if self.rccl:
+            out = torch.empty(self.world * g.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
+            self.dist.all_gather_into_tensor(out, g.contiguous())
+            return out
+        parts = [torch.empty(g.shape, dtype=g.dtype) for _ in range(self.world)]   # rehearsal path (gloo, host)
+        self.dist.all_gather(parts, g.cpu().contiguous())
+        return torch.cat(parts).to(g.device)
 
     def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
         m = self.m
@@ -58,8 +68,17 @@ class DataParallelFFC(object):
         loss1 = self._pass(y, x, y_label, x_label, False)     # ffc.py:266
         return loss1 + loss2
 
-    def reduce_gradients(self):
+    def reduce_gradients(self, optimizer=None):
         """Sum the probe-net gradients over ranks (one all-reduce on a flat buffer)."""
+        flat = optimizer.flat_grad() if optimizer is not None and hasattr(optimizer, "flat_grad") else None
+        if flat is not None:
+            if self.rccl:
+                self.dist.all_reduce(flat)
+            else:
+                c = flat.cpu()
+                self.dist.all_reduce(c)
+                flat.copy_(c)
+            return
         grads = [p.grad for p in self.m.probe_net.parameters() if p.requires_grad and p.grad is not None]
         flat = torch._utils._flatten_dense_tensors(grads)
         self.dist.all_reduce(flat)
