@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--feat", type=int, default=512)
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-glds", type=int, default=-1, help="A/B switch for the conv kernel variant (vlsfr_set_option)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the "
                     "multi-process path on a 1-GPU box")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -163,6 +164,8 @@ def main():
         return loss
 
     L = _lib.lib()
+    if args.conv_glds >= 0:
+        L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(args.conv_glds))
     note("model on device, pool %d slots; warm-up" % Q)
     for i in range(args.warmup):
         one_step(i)

@@ -276,6 +276,9 @@ int vlsfr_ema(const int64_t* table_dev, int32_t n_chunks, float m, void* stream)
  *    (2 * pixels * Cout * R*S*Cin per launch) and launch count.  Used by bench.py's roofline leg.
  * ---------------------------------------------------------------------------------------- */
 void vlsfr_profile_enable(int32_t on);
+/* tuning switches for A/B measurements: "conv_glds" (1 = LDS-DMA pipelined conv kernel, default;
+ * 0 = register-staged kernel) */
+int vlsfr_set_option(const char* name, int32_t value);
 int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops, int64_t* launches);
 void vlsfr_profile_reset(void);
 

@@ -1,0 +1,20 @@
+"""Micro-benchmark of one convolution shape (diagnostic; used under rocprofv3 --pmc)."""
+import ctypes, sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vlsfr_amd import ops, _lib
+variant = int(sys.argv[1]); B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+cin = cout = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+hw = int(sys.argv[4]) if len(sys.argv) > 4 else 14
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
+L = _lib.lib(); L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(variant))
+x = torch.randn(B, hw, hw, cin, device="cuda").to(torch.bfloat16)
+w = (torch.randn(cout, 3, 3, cin, device="cuda") * 0.05).to(torch.bfloat16)
+d = ops.ConvDesc(B, hw, hw, cin, cout, 3, 3, 1, 1)
+stats = ops.new_sums(cout, "cuda")
+for _ in range(3): ops.conv2d_fwd(x, w, d, stats=stats)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(iters): ops.conv2d_fwd(x, w, d, stats=stats)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
+fl = 2.0 * B * hw * hw * cout * 9 * cin
+print("variant %d B=%d %dx%d@%d: %.1f us, %.1f TFLOP/s" % (variant, B, cin, cout, hw, dt * 1e6, fl / dt / 1e12))

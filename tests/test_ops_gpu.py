@@ -37,8 +37,19 @@ IR_SHAPES = [
 ]
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=["regstage", "glds64x4", "glds32x4", "glds64x2"])
+def conv_variant(request):
+    """Every implicit-GEMM kernel variant (register-staged, and the LDS-DMA rings) must agree."""
+    import ctypes
+    from vlsfr_amd import _lib
+    L = _lib.lib()
+    L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(request.param))
+    yield request.param
+    L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(-1))
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,pad,hw", IR_SHAPES)
-def test_conv_fwd_dgrad_wgrad(cin, cout, k, stride, pad, hw):
+def test_conv_fwd_dgrad_wgrad(cin, cout, k, stride, pad, hw, conv_variant):
     from vlsfr_amd import ops
     torch.manual_seed(cin * 7 + cout + k + stride + hw)
     N = 3

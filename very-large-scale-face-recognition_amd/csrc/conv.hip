@@ -17,6 +17,8 @@
 //   slow axis of both NHWC operands, so both tiles go to LDS pixel-major as they lie in memory and
 //   are read back with ds_read_b64_tr_b16 (hardware transpose).  Split over the pixel range with
 //   fp32 atomics into the (pre-zeroed or accumulating) gradient buffer.
+#include <cstring>
+#include <utility>
 #include <vector>
 
 #include "hip_common.h"
@@ -33,6 +35,8 @@ struct ProfRec {
   int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad
 };
 bool g_prof_on = false;
+#define VLSFR_DEFAULT_CONV_VARIANT 3
+int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -270,6 +274,254 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_glds_kernel — the same implicit GEMM with a 4-stage LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write) and one raw barrier per 64-deep
+// k-tile.  The register-staged kernel above keeps one k-tile in flight per workgroup and is bound by
+// memory latency (~10x the MFMA time of a tile); here three tiles (96 KB) are in flight per CU behind
+// counted s_waitcnt vmcnt(N), so the MFMAs of tile t overlap the loads of tiles t+1..t+3.
+//   * LDS image per stage: A [BM][64] and B [BN][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled
+//     with (row & 7).  An LDS-DMA wave-instruction writes 1 KiB linearly (8 rows x 8 chunks), so the
+//     swizzle is applied to the per-lane SOURCE address: lane (r = lane >> 3, c = lane & 7) fetches
+//     logical chunk c ^ r of its row.
+//   * padding / out-of-range rows read a 16-byte zero page instead (the DMA always writes its lanes).
+//   * fragment reads are inline-asm ds_read_b128 behind an explicit lgkmcnt(0): the compiler cannot
+//     see that they touch the DMA'd bytes, so it inserts no vmcnt(0) in front of them.
+// ------------------------------------------------------------------------------------------------
+__device__ uint4 g_zero_page[4] = {};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read128_asm(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int STRIDE, int BASE, int... I>
+__device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::integer_sequence<int, I...>) {
+  ((f[I] = lds_read128_asm<BASE + I * STRIDE>(addr)), ...);
+}
+
+template <int BM, int BN, int BK, int NST>
+__global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int RSB = BK * 2;           // LDS row bytes
+  constexpr int CPR = BK / 8;           // 16-byte chunks per row
+  constexpr int RPI = 1024 / RSB;       // rows covered by one 1-KiB LDS-DMA wave-instruction
+  constexpr int AI = BM / (4 * RPI);    // LDS-DMA instructions per wave and stage, weight tile
+  constexpr int BI = BN / (4 * RPI);    // pixel tile
+  constexpr int STAGE = (BM + BN) * RSB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = a.Nimg * a.Ho * a.Wo;
+  const int K = a.R * a.S * a.C;
+  const int m0 = blockIdx.y * BM;
+  const int p0 = blockIdx.x * BN;
+  const int nkt = K / BK;
+  const int per = (nkt + a.splitk - 1) / a.splitk;
+  const int kt0 = blockIdx.z * per;
+  const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
+  const int nk = kt1 - kt0;
+  if (nk <= 0) return;
+
+  // ---- per-lane gather descriptors
+  const int rsub = lane / CPR;
+  const int lchunk = (lane % CPR) ^ swz<BK>(rsub);   // logical 16-byte chunk this lane fetches
+  const u16* zero = (const u16*)g_zero_page;
+  const u16* a_ptr[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + (wave * AI + i) * RPI + rsub;
+    a_ptr[i] = m < a.Mrows ? a.w + (size_t)m * K + lchunk * 8 : nullptr;
+  }
+  const u16* b_ptr[BI];
+  uint32_t b_mask[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int p = p0 + (wave * BI + i) * RPI + rsub;
+    const bool okp = p < P;
+    const int pp = okp ? p : 0;
+    const int n = pp / (a.Ho * a.Wo);
+    const int rem = pp - n * a.Ho * a.Wo;
+    const int ho = rem / a.Wo;
+    const int wo = rem - ho * a.Wo;
+    int bh, bw;
+    if (a.mode == 0) {
+      bh = ho * a.stride - a.pad;
+      bw = wo * a.stride - a.pad;
+    } else if (a.stride == 1) {
+      bh = ho + a.pad;
+      bw = wo + a.pad;
+    } else {
+      bh = (ho + a.pad) >> 1;
+      bw = (wo + a.pad) >> 1;
+    }
+    uint32_t mask = 0;
+    for (int r = 0; r < a.R; ++r)
+      for (int s = 0; s < a.S; ++s) {
+        int hi, wi;
+        bool ok = okp;
+        if (a.mode == 0) {
+          hi = bh + r;
+          wi = bw + s;
+        } else if (a.stride == 1) {
+          hi = bh - r;
+          wi = bw - s;
+        } else {
+          ok = ok && !(((ho + a.pad - r) | (wo + a.pad - s)) & 1);
+          hi = bh - (r >> 1);
+          wi = bw - (s >> 1);
+        }
+        ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        if (ok) mask |= 1u << (r * a.S + s);
+      }
+    b_mask[i] = mask;
+    b_ptr[i] = a.x + (((int64_t)n * a.H + bh) * a.W + bw) * a.C + lchunk * 8;   // tap (0,0); only dereferenced when valid
+  }
+
+  // k-tile cursor of the NEXT tile to issue, advanced incrementally (no divisions in the loop)
+  int is_k0 = kt0 * BK;
+  int is_tap = is_k0 / a.C;
+  int is_c0 = is_k0 - is_tap * a.C;
+  int is_r = is_tap / a.S;
+  int is_s = is_tap - is_r * a.S;
+  auto issue = [&](int stage) {
+    int toff;
+    if (a.mode == 0) toff = (is_r * a.W + is_s) * a.C;
+    else if (a.stride == 1) toff = -(is_r * a.W + is_s) * a.C;
+    else toff = -((is_r >> 1) * a.W + (is_s >> 1)) * a.C;
+    toff += is_c0;
+    const uint32_t bit = 1u << is_tap;
+    char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const u16* src = a_ptr[i] ? a_ptr[i] + is_k0 : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * AI + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const u16* src = (b_mask[i] & bit) ? b_ptr[i] + toff : zero;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + BM * RSB + (wave * BI + i) * 1024), 16, 0,
+                                       0);
+    }
+    is_k0 += BK;
+    is_c0 += BK;
+    if (is_c0 >= a.C) {
+      is_c0 = 0;
+      ++is_tap;
+      if (++is_s >= a.S) {
+        is_s = 0;
+        ++is_r;
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const int pre = nk < NST - 1 ? nk : NST - 1;
+  for (int s = 0; s < pre; ++s) issue(s);
+
+  for (int it = 0; it < nk; ++it) {
+    // tiles issued after tile `it` may stay in flight: min(NST - 2, nk - 1 - it) of them, (AI + BI) DMAs each
+    const int later = (nk - 1 - it) < (NST - 2) ? (nk - 1 - it) : (NST - 2);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + NST - 1 < nk) issue((it + NST - 1) % NST);
+    const uint32_t sbase = lds0 + (uint32_t)((it % NST) * STAGE);
+    // all fragment reads of the tile are issued up front; the MFMAs of k-step kk start as soon as
+    // its (MT + NT) reads have returned (counted lgkmcnt), the later reads land underneath them
+    constexpr int KK = BK / 32;
+    bf16x8 fa[KK][MT], fb[KK][NT];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const uint32_t rd = sbase + (uint32_t)(r16 * RSB + (((kk * 4 + h) ^ swz<BK>(r16)) << 4));
+      lds_read_frags<16 * RSB, 0>(fa[kk], rd + (uint32_t)(wm * (BM / 2) * RSB), std::make_integer_sequence<int, MT>{});
+      lds_read_frags<16 * RSB, BM * RSB>(fb[kk], rd + (uint32_t)(wn * (BN / 2) * RSB),
+                                         std::make_integer_sequence<int, NT>{});
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk + 1 < KK) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((KK - 1 - kk) * (MT + NT)) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[kk][i], fb[kk][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
+  float cs[MT][4], cq[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int p = p0 + wn * (BN / 2) + j * 16 + r16;
+    if (p >= P) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h;
+      if (m >= a.Mrows) continue;
+      if (a.out_f32) {
+        float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
+        if (a.splitk > 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
+        } else {
+          *(f32x4*)dst = acc[i][j];
+        }
+      } else {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (__bf16)acc[i][j][e];
+          const float f = (float)o[e];
+          cs[i][e] += f;
+          cq[i][e] += f * f;
+        }
+        *(bf16x4*)((u16*)a.y + (size_t)p * a.Mrows + m) = o;
+      }
+    }
+  }
+  if (a.stats) {   // fused BatchNorm statistics: reduce over the 16 pixel lanes, one atomic per channel and wave
+    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = cs[i][e], q = cq[i][e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          s += __shfl_xor(s, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h + e;
+        if (r16 == 0 && m < a.Mrows) {
+          atomicAdd(dst + m, s);
+          atomicAdd(dst + a.Mrows + m, q);
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct WgradArgs {
   const u16* dy;     // [P, Cout] bf16
   const u16* x;      // [Nimg, H, W, C] bf16 (forward input)
@@ -421,6 +673,21 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
 
 inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
+template <int BM, int BN, int BK, int NST>
+int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
+  constexpr int lds = NST * (BM + BN) * BK * 2;
+  static bool attr_set = false;
+  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return hip_fail(e, "conv_igemm_glds: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  return VLSFR_OK;
+}
+
 template <int BM, int BN>
 void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
@@ -433,7 +700,15 @@ int run_igemm(ConvArgs a, hipStream_t st) {
   ProfScope prof(st, 0, 2.0 * P * (double)a.Mrows * a.R * a.S * a.C);
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
-  if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);
+  const bool glds_ok = g_use_glds && a.C % 64 == 0 && a.R * a.S <= 9 && (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 31);
+  if (glds_ok) {
+    int rc;
+    const bool big = a.Mrows >= 128;
+    if (g_use_glds == 1) rc = big ? launch_igemm_glds<128, 128, 64, 4>(a, P, st) : launch_igemm_glds<64, 128, 64, 4>(a, P, st);
+    else if (g_use_glds == 2) rc = big ? launch_igemm_glds<128, 128, 32, 4>(a, P, st) : launch_igemm_glds<64, 128, 32, 4>(a, P, st);
+    else rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    if (rc != VLSFR_OK) return rc;
+  } else if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);
   else if (a.Mrows >= 128) launch_igemm<128, 64>(a, P, st);
   else launch_igemm<64, 128>(a, P, st);
   VLSFR_HIP_CHECK_LAUNCH("conv_igemm launch");
@@ -445,6 +720,14 @@ int run_igemm(ConvArgs a, hipStream_t st) {
 extern "C" {
 
 void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
+
+int vlsfr_set_option(const char* name, int32_t value) {
+  if (name && !strcmp(name, "conv_glds")) {
+    g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  return fail(VLSFR_EINVAL, "vlsfr_set_option: unknown option");
+}
 
 int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops, int64_t* launches) {
   if (!total_ms || !total_flops || !launches) return fail(VLSFR_EINVAL, "vlsfr_profile_collect: null argument");

@@ -52,6 +52,7 @@ struct SweepArgs {
   float* topk_val;       // [n_chunks, Bp, 4, KTOP]
   int32_t* topk_idx;
   int32_t Bp;
+  int32_t n_rowblk;
 };
 
 template <int DP>
@@ -80,11 +81,18 @@ __global__ __launch_bounds__(256, 1) void head_sweep_kernel(SweepArgs a) {
   const int wave = tid >> 6;
   const int r16 = lane & 15;
   const int h = lane >> 4;
-  const int chunk = blockIdx.x;
+  // XCD-aware block order: workgroups are dealt round-robin over the 8 XCDs, so ids that are equal
+  // mod 8 share an L2.  The row blocks of one column chunk get ids 8 apart inside one group of
+  // 8 * n_rowblk consecutive ids: they run at the same time on the same XCD and the chunk is fetched
+  // from HBM once instead of once per row block.
+  const int nrb = a.n_rowblk;
+  const int within = blockIdx.x % (8 * nrb);
+  const int chunk = (blockIdx.x / (8 * nrb)) * 8 + (within & 7);
+  const int rowblk = within >> 3;
   const int64_t c0 = (int64_t)chunk * a.chunk_cols;
   const int64_t c1 = (c0 + a.chunk_cols < a.Q) ? c0 + a.chunk_cols : a.Q;
   const int ntiles = (int)((c1 - c0 + TQ - 1) / TQ);
-  const int row_base = blockIdx.y * ROWS_WG + wave * 16;
+  const int row_base = rowblk * ROWS_WG + wave * 16;
   const bool wave_active = row_base < a.B;     // wave-uniform
 
   // ---- special-column bitmap of this chunk
@@ -681,6 +689,7 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   }
   pl->chunk_cols = (int)per * TQ;
   pl->n_chunks = (int)((c->Q + pl->chunk_cols - 1) / pl->chunk_cols);
+  pl->n_chunks = (pl->n_chunks + 7) & ~7;   // multiple of 8 for the XCD-aware block order (extra chunks are empty)
   pl->n_sets = (c->loss_type == 2) ? 2 : 1;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -806,7 +815,8 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   a.topk_val = (float*)(ws + pl.off_tv);
   a.topk_idx = (int32_t*)(ws + pl.off_ti);
   a.Bp = pl.Bp;
-  const dim3 grid(pl.n_chunks, pl.n_rowblk);
+  a.n_rowblk = pl.n_rowblk;
+  const dim3 grid(pl.n_chunks * pl.n_rowblk);
   for (int set = 0; set < pl.n_sets; ++set) {
     a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
     a.part_l = (float*)(ws + pl.off_l) + set * rowsz;
