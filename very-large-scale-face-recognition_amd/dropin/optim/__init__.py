@@ -1,0 +1,4 @@
+"""Drop-in for the reference's top-level `optim` package."""
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))))
+from vlsfr_amd.optim import get_optim_scheduler  # noqa: E402,F401
