@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--net", default="ir50")
-    ap.add_argument("--batch", type=int, default=64, help="--batch_size of the reference: rows of x and of y per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="--batch_size of the reference: rows of x and of y per GPU")
     ap.add_argument("--identities", type=int, default=1 << 20)
     ap.add_argument("--queue", type=int, default=0, help="pool slots (0 = one per identity, full residency)")
     ap.add_argument("--feat", type=int, default=512)

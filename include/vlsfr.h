@@ -184,6 +184,17 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * 5b. Depthwise convolutions (device).  Replaces nn.Conv2d(groups = C) of MobileFaceNet
+ *     (mobilefacenet_def.py:39 3x3 stride 1/2 pad 1; :60,88 7x7 valid), forward / input gradient /
+ *     weight gradient.  d->Cin == d->Cout == C (C % 8 == 0), square filter <= 7.  x, y, dy, dx:
+ *     NHWC bf16; w: fp32 [C][R*S] (the parameter's own memory); dw: fp32 [C][R*S] accumulated (+=);
+ *     stats (optional): BatchNorm statistics [VLSFR_BN_REPL][2][C] of y, pre-zeroed.
+ * ---------------------------------------------------------------------------------------- */
+int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, float* stats, void* stream);
+int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w, void* dx, void* stream);
+int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * 6. Normalisation / activation / layout kernels (device).  Replaces nn.BatchNorm2d in training
  *    mode (resnet_arcface.py:35,37,40,75,93), nn.PReLU (:38,76), the residual add (:54), the
  *    BatchNorm1d + F.normalize embedding tail (:96-98,151) and the layout/precision conversions.
@@ -216,15 +227,18 @@ int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, c
                     float* running_mean, float* running_var, float* z, float* xhat, float* invstd,
                     float* emb, float* inv_norm, int32_t B, int32_t D, float eps, float momentum,
                     void* stream);
+/* dbeta (+=) is required; dfc_bias / dgamma (+=) may be NULL (no bias in front / frozen weight) */
 int vlsfr_embed_bwd(const float* demb, const float* emb, const float* inv_norm, const float* xhat,
                     const float* invstd, const float* gamma, float* dz, void* dfc_bf16, float* dbeta,
-                    float* dfc_bias, int32_t B, int32_t D, void* stream);
+                    float* dfc_bias, float* dgamma, int32_t B, int32_t D, void* stream);
 /* fp32 [rows][taps][C] -> bf16 [rows][Kp] (zero padded to Kp >= taps*C) and optionally the
  * dgrad operand wT bf16 [C][taps][rows] */
 int vlsfr_cast_weight(const float* w, void* w_bf16, void* wT_bf16, int32_t rows, int32_t taps, int32_t C,
                       int32_t Kp, void* stream);
-/* fp32 NCHW image [N,3,H,W] -> bf16 im2col rows [N*H*W][32] of the 3x3 pad-1 stem (k=(r*3+s)*3+c) */
-int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, void* stream);
+/* fp32 NCHW image [N,3,H,W] -> bf16 im2col rows [N*Ho*Wo][32] of the 3x3 pad-1 stem, stride 1
+ * (iResNet, resnet_arcface.py:74) or 2 (MobileFaceNet, mobilefacenet_def.py:80); k=(r*3+s)*3+c */
+int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, int32_t stride,
+                      void* stream);
 int vlsfr_unpad_add(const float* src, float* dst, int32_t rows, int32_t Ksrc, int32_t Kdst, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -256,6 +270,28 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
                           void* stream);
 int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const float* const* params,
                            float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 7b. MobileFaceNet backbone executor: same contract as section 7 for reference
+ *     model/mobilefacenet_def.py:77-123 (MobileFaceNet.forward, training mode).  Parameter order =
+ *     registration order of the reference module (conv1.conv.weight, conv1.bn.weight, conv1.bn.bias,
+ *     conv1.prelu.weight, dw_conv1.*, blocks.0.conv.0.weight, ... linear1.bn.bias); depthwise weights
+ *     are used in place as fp32 [C][k*k].
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_mobilenet vlsfr_mobilenet;
+int vlsfr_mobilenet_create(int32_t feat_dim, int32_t batch, int32_t image_hw, vlsfr_mobilenet** out);
+void vlsfr_mobilenet_destroy(vlsfr_mobilenet* n);
+int32_t vlsfr_mobilenet_num_params(const vlsfr_mobilenet* n);
+int32_t vlsfr_mobilenet_num_bn(const vlsfr_mobilenet* n);
+size_t vlsfr_mobilenet_wcache_bytes(const vlsfr_mobilenet* n);
+size_t vlsfr_mobilenet_ctx_bytes(const vlsfr_mobilenet* n);
+size_t vlsfr_mobilenet_scratch_bytes(const vlsfr_mobilenet* n);
+int vlsfr_mobilenet_prepare_weights(const vlsfr_mobilenet* n, const float* const* params, void* wcache, void* stream);
+int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const float* const* params,
+                            float* const* running, const void* wcache, void* ctx, void* scratch, float* emb_out,
+                            void* stream);
+int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const float* const* params,
+                             float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8. Parameter sweeps (device), one launch over all tensors.

@@ -209,3 +209,44 @@ def test_embedding_tail(B, D):
     dfc = ops.embed_bwd(de.cuda(), emb, saved, gamma.cuda(), dbeta, dfcb)
     close(dfc, fr.grad, 1e-2)
     close(dbeta, ber.grad, 1e-4)
+
+
+@pytest.mark.parametrize("C,k,stride,pad,hw", [(64, 3, 1, 1, 14), (128, 3, 2, 1, 14), (256, 3, 2, 1, 7), (512, 3, 1, 1, 7),
+                                              (512, 7, 1, 0, 7), (24, 3, 2, 1, 9)])
+def test_depthwise_conv_fwd_dgrad_wgrad(C, k, stride, pad, hw):
+    """MobileFaceNet depthwise 3x3 (stride 1 / 2) and the 7x7 valid 'linear7' layer."""
+    from vlsfr_amd import ops
+    torch.manual_seed(C + k + stride + hw)
+    N = 3
+    x = bf(torch.randn(N, C, hw, hw))
+    w = torch.randn(C, 1, k, k) * 0.3
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride, pad, 1, C)
+    dy = bf(torch.randn_like(y_ref))
+    y_ref.backward(dy)
+    d = ops.ConvDesc(N, hw, hw, C, C, k, k, stride, pad)
+    xg = nhwc(x).cuda().to(torch.bfloat16)
+    wg = w.reshape(C, k * k).contiguous().cuda()
+    stats = ops.new_sums(C, "cuda")
+    y = ops.dwconv_fwd(xg, wg, d, stats=stats)
+    close(y.permute(0, 3, 1, 2), bf(y_ref.detach()), 1e-2)
+    yf = y.float().reshape(-1, C)
+    close(stats.sum(0)[0], yf.sum(0).cpu(), 1e-3)
+    close(stats.sum(0)[1], (yf * yf).sum(0).cpu(), 1e-3)
+    dyg = nhwc(dy).cuda().to(torch.bfloat16)
+    close(ops.dwconv_dgrad(dyg, wg, d).permute(0, 3, 1, 2), xr.grad, 1e-2)
+    dw = ops.dwconv_wgrad(dyg, xg, d)
+    close(dw.reshape(C, 1, k, k), wr.grad, 2e-3)
+
+
+def test_stem_im2col_stride2_matches_conv():
+    from vlsfr_amd import ops
+    torch.manual_seed(1)
+    N, H = 2, 20
+    x = torch.randn(N, 3, H, H)
+    w = bf(torch.randn(64, 3, 3, 3) * 0.1)
+    cols = ops.stem_im2col(x.cuda(), stride=2)
+    wb, _ = ops.cast_weight(w.permute(0, 2, 3, 1).contiguous().cuda(), 64, 1, 27, Kp=32, transpose=False)
+    d = ops.ConvDesc(N, H // 2, H // 2, 32, 64, 1, 1, 1, 0)
+    y = ops.conv2d_fwd(cols, wb, d)
+    close(y.permute(0, 3, 1, 2), bf(F.conv2d(bf(x), w, None, 2, 1)), 1e-2)

@@ -45,10 +45,11 @@ def build_ffc(z, net_type, precise_head=True):
     return m, x, y, torch.from_numpy(inp["xl"]), torch.from_numpy(inp["yl"])
 
 
-def test_irtiny_step_matches_reference_golden():
+@pytest.mark.parametrize("tag", ["irtiny", "mobile"])
+def test_step_matches_reference_golden(tag):
     from vlsfr_amd.optim import get_optim_scheduler
-    z = np.load(os.path.join(G, "step_irtiny.npz"))
-    m, x, y, xl, yl = build_ffc(z, "irtiny")
+    z = np.load(os.path.join(G, "step_%s.npz" % tag))
+    m, x, y, xl, yl = build_ffc(z, tag)
     cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
                milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])
     opt, sched = get_optim_scheduler([p for p in m.parameters() if p.requires_grad], cfg)
@@ -60,23 +61,27 @@ def test_irtiny_step_matches_reference_golden():
     loss.backward()
     hook.remove()
     torch.cuda.synchronize()
-    # embeddings, loss
-    assert min_cos(embs[0], z["emb_probe_x"]) >= 0.999
-    assert min_cos(embs[1], z["emb_probe_y"]) >= 0.999
-    np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=2e-2)
+    # embeddings, loss.  MobileFaceNet stacks 50 bf16 conv + train-mode BN layers and ends in two
+    # BatchNorms over only 8 samples (1x1 maps), so its bf16 round-off is amplified more than the
+    # 4-block iResNet's: the bounds are looser there (scripts/bf16_sensitivity.py calibrates this on
+    # the CPU: fp32-vs-fp64 deviation x 2^15 predicts ~9 % for MobileFaceNet, ~3 % for the iResNet).
+    tol = dict(irtiny=dict(cos=0.999, loss=2e-2, gnorm=8e-2, gl2=0.1), mobile=dict(cos=0.995, loss=3e-2, gnorm=0.25, gl2=0.45))[tag]
+    assert min_cos(embs[0], z["emb_probe_x"]) >= tol["cos"]
+    assert min_cos(embs[1], z["emb_probe_y"]) >= tol["cos"]
+    np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=tol["loss"])
     # gradients
     names = [str(n) for n in z["grad_names"]]
     pn = dict(m.probe_net.named_parameters())
     gn = np.asarray([float(pn[n].grad.norm()) for n in names])
     big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
-    np.testing.assert_allclose(gn[big], z["grad_norms"][big], rtol=8e-2)
+    np.testing.assert_allclose(gn[big], z["grad_norms"][big], rtol=tol["gnorm"])
     for key in z.files:
         if key.startswith("grad/"):
             want = z[key]
             if np.abs(want).max() < 1e-6:
                 continue    # bias in front of a BatchNorm: exactly zero gradient in exact arithmetic
             got = sample(pn[key[5:]].grad.detach().cpu().numpy())
-            assert rel_l2(got, want) < 0.1, (key, rel_l2(got, want))
+            assert rel_l2(got, want) < tol["gl2"], (key, rel_l2(got, want))
     # optimizer step + EMA
     opt.step()
     torch.cuda.synchronize()
@@ -84,7 +89,7 @@ def test_irtiny_step_matches_reference_golden():
     for key in z.files:
         if key.startswith("after/"):
             got = sample(pn[key[6:]].detach().cpu().numpy())
-            assert rel_l2(got, z[key]) < 0.1, (key, rel_l2(got, z[key]))   # lr * gradient dominates: same bound as the gradients
+            assert rel_l2(got, z[key]) < tol["gl2"], (key, rel_l2(got, z[key]))   # lr * gradient dominates: same bound as the gradients
         elif key.startswith("gallery_after/"):
             np.testing.assert_allclose(sample(gp[key[14:]].detach().cpu().numpy()), z[key], rtol=1e-5, atol=1e-6)
         elif key.startswith("buf/"):
@@ -96,7 +101,7 @@ def test_irtiny_step_matches_reference_golden():
     assert m.queue_position_dict.values() == z["qp_final"].astype(int).tolist()
     qf, qw = m.queue.cpu().numpy(), z["queue_final"]
     changed = np.abs(qw - z["queue_warm"]).max(axis=2) > 0
-    assert min_cos(qf[changed], qw[changed]) >= 0.999           # rows written by the gallery net
+    assert min_cos(qf[changed], qw[changed]) >= tol["cos"]           # rows written by the gallery net
     np.testing.assert_array_equal(qf[~changed], qw[~changed].astype(np.float32))
 
 
@@ -146,3 +151,19 @@ def test_ir18_two_steps_vs_oracle():
     # train-mode-BN stack deviate 3-10 % from float64 (scripts/diag_grad_profile.py shows the error
     # growing smoothly from 1 % at the head to 10 % at the stem, no jump at any layer type)
     assert rel_l2(w_g, w_o) < 0.25
+
+
+def test_main_train_loop(tmp_path):
+    """The training driver (main.py mirror): a few iterations on synthetic faces, checkpoint format of
+    the reference (main.py:85)."""
+    from vlsfr_amd.main import parse_args, train
+    conf = parse_args(["--net_type", "irtiny", "--feat_dim", "32", "--queue_size", "64", "--batch_size", "8",
+                       "--print_freq", "3", "--iters_per_epoch", "6", "--num_class", "500", "--saved_dir", str(tmp_path)])
+    logs = []
+    net, loss = train(conf, log=logs.append)
+    assert np.isfinite(float(loss.detach())) and len(logs) == 2
+    ck = torch.load(os.path.join(str(tmp_path), "2.pt"), weights_only=False)
+    assert set(ck) == {"state_dict", "lru", "fc", "qp"}
+    assert ck["fc"].shape == (2, 64, 32) and len(ck["qp"]) == 64 and len(ck["lru"]) == len(net.lru.state_dict())
+    assert "layer1.0.conv1.weight" in ck["state_dict"]
+    assert int(ck["state_dict"]["bn1.num_batches_tracked"]) == 12      # two probe forwards per iteration

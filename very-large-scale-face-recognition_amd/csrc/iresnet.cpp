@@ -332,7 +332,7 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
   // Every BatchNorm's batch statistics are accumulated by the kernel that PRODUCES its input (conv
   // epilogue or the previous bn_apply), so no tensor is read just to be averaged.
   // stem (resnet_arcface.py:140-142)
-  RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, B, S, S, st));
+  RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, B, S, S, 1, st));
   RUN(vlsfr_conv2d_fwd(&n->stem.d, ctx + n->off_cols, wc + n->stem.off_wb, ctx + n->off_c0, 1, 0, sums_of(n->stem_bn), st));
   RUN(bn_forward(n->stem_bn, ctx + n->off_c0, ctx + n->off_a0, (int64_t)B * S * S, S * S, nullptr,
                  sums_of(n->blocks[0].bn1), 0, params, running, ctx, st));
@@ -391,7 +391,7 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
   // embedding tail, fc
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd),
-                      params[n->p_feat_w], sc.dz, sc.dfc, grads[n->p_feat_b], grads[n->p_fc_b], B, n->D, st));
+                      params[n->p_feat_w], sc.dz, sc.dfc, grads[n->p_feat_b], grads[n->p_fc_b], nullptr, B, n->D, st));
   RUN(vlsfr_conv2d_wgrad(&n->fc.d, sc.dfc, ctx + n->off_flat, grads[n->fc.p_w], 0, st));
   char* dflat = sc.g[0];
   RUN(vlsfr_conv2d_dgrad(&n->fc.d, sc.dfc, wc + n->fc.off_wT, dflat, st));

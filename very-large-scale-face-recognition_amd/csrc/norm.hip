@@ -447,7 +447,8 @@ struct EmbedBwdArgs {
   float* dz;              // [B, D] scratch
   u16* dfc;               // [B, D] bf16: gradient wrt the fc output, operand of the fc dgrad / wgrad
   float* dbeta;           // features.bias grad (+=)
-  float* dfc_bias;        // fc.bias grad (+=)
+  float* dfc_bias;        // fc.bias grad (+=) or nullptr
+  float* dgamma;          // BN weight grad (+=) or nullptr (frozen in the iResNet tail)
   int B, D;
 };
 
@@ -478,6 +479,7 @@ __global__ void embed_bn_bwd_kernel(EmbedBwdArgs a) {
     s1 += dzv * a.xhat[(size_t)b * a.D + d];
   }
   a.dbeta[d] += s0;
+  if (a.dgamma) a.dgamma[d] += s1;
   const float k = g * a.invstd[d];
   const float m0 = g * s0 / a.B, m1 = g * s1 / a.B;
   float sb = 0.f;
@@ -488,7 +490,7 @@ __global__ void embed_bn_bwd_kernel(EmbedBwdArgs a) {
     a.dfc[i] = f2bf(dv);
     sb += dv;
   }
-  a.dfc_bias[d] += sb;
+  if (a.dfc_bias) a.dfc_bias[d] += sb;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -513,13 +515,14 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* w, u16* w
   }
 }
 
-// stem: fp32 NCHW image [N,3,H,W] -> bf16 im2col rows [N*H*W][32], k = (r*3 + s)*3 + c, 3x3 pad 1 stride 1
-__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* x, u16* out, int N, int H, int W) {
-  const int64_t P = (int64_t)N * H * W;
+// stem: fp32 NCHW image [N,3,H,W] -> bf16 im2col rows [N*Ho*Wo][32], k = (r*3 + s)*3 + c, 3x3 pad 1, stride 1 or 2
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* x, u16* out, int N, int H, int W, int stride) {
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  const int64_t P = (int64_t)N * Ho * Wo;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
-    const int n = (int)(p / (H * W));
-    const int rem = (int)(p - (int64_t)n * H * W);
-    const int ho = rem / W, wo = rem - ho * W;
+    const int n = (int)(p / (Ho * Wo));
+    const int rem = (int)(p - (int64_t)n * Ho * Wo);
+    const int ho = rem / Wo, wo = rem - ho * Wo;
     float v[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) v[k] = 0.f;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* x, u16* o
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const int hi = ho + r - 1, wi = wo + s - 1;
+        const int hi = ho * stride + r - 1, wi = wo * stride + s - 1;
         if (hi >= 0 && hi < H && wi >= 0 && wi < W) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) v[(r * 3 + s) * 3 + c] = x[(((size_t)n * 3 + c) * H + hi) * W + wi];
@@ -636,12 +639,11 @@ int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, c
 }
 
 int vlsfr_embed_bwd(const float* demb, const float* emb, const float* inv_norm, const float* xhat, const float* invstd,
-                    const float* gamma, float* dz, void* dfc_bf16, float* dbeta, float* dfc_bias, int32_t B,
-                    int32_t D, void* stream) {
-  if (!demb || !emb || !inv_norm || !xhat || !invstd || !gamma || !dz || !dfc_bf16 || !dbeta || !dfc_bias || B <= 0 ||
-      D <= 0)
+                    const float* gamma, float* dz, void* dfc_bf16, float* dbeta, float* dfc_bias, float* dgamma,
+                    int32_t B, int32_t D, void* stream) {
+  if (!demb || !emb || !inv_norm || !xhat || !invstd || !gamma || !dz || !dfc_bf16 || !dbeta || B <= 0 || D <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_embed_bwd: bad argument");
-  EmbedBwdArgs a{demb, emb, inv_norm, xhat, invstd, gamma, dz, (u16*)dfc_bf16, dbeta, dfc_bias, B, D};
+  EmbedBwdArgs a{demb, emb, inv_norm, xhat, invstd, gamma, dz, (u16*)dfc_bf16, dbeta, dfc_bias, dgamma, B, D};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(embed_norm_bwd_kernel, dim3(B), dim3(256), 0, st, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_embed_bwd norm");
@@ -660,10 +662,12 @@ int vlsfr_cast_weight(const float* w, void* w_bf16, void* wT_bf16, int32_t rows,
   return VLSFR_OK;
 }
 
-int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, void* stream) {
-  if (!x_nchw || !out || N <= 0 || H <= 0 || W <= 0) return fail(VLSFR_EINVAL, "vlsfr_stem_im2col: bad argument");
-  hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks_for((int64_t)N * H * W, 256, 4096)), dim3(256), 0,
-                     (hipStream_t)stream, x_nchw, (u16*)out, N, H, W);
+int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, int32_t stride, void* stream) {
+  if (!x_nchw || !out || N <= 0 || H <= 0 || W <= 0 || stride < 1 || stride > 2)
+    return fail(VLSFR_EINVAL, "vlsfr_stem_im2col: bad argument");
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks_for((int64_t)N * Ho * Wo, 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, x_nchw, (u16*)out, N, H, W, stride);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_stem_im2col");
   return VLSFR_OK;
 }

@@ -1,0 +1,153 @@
+"""Training driver with the loop shape and CLI of the reference's main.py (main.py:23-86
+train_one_epoch, :88-143 train, :146-170 argparse), on the MI355X path.
+
+Differences, all forced by scope: the LMDB loaders of the reference do not import
+(`util/lmdb_loader.py:4`), so batches come from `SyntheticFaces`, which honours the loader's output
+contract (float32 CHW, (v - 127.5) * 0.0078125, labels; pair dataset -> (img1, img2, id)); no
+autocast / GradScaler (bf16 MFMA operands with fp32 accumulation need no loss scaling); one process per
+GPU under torch.distributed when WORLD_SIZE > 1 (parallel.py).  Checkpoints keep the reference's
+dictionary (`main.py:85`): state_dict / lru / fc / qp.
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from .ffc import FFC
+from .optim import get_optim_scheduler
+
+OPTIM_CONFIG = dict(scheduler="multistep", epochs=1, warmup=0, patience=4, milestones=[8, 14, 17],
+                    gammas=[0.1, 0.1, 0.1], LR_min=1e-5, optim="SGD", LR=0.1, decay=1e-4, momentum=0.9,
+                    nesterov=True)     # config/optim_config:1-14
+
+
+def load_config(path):
+    """Typed-JSON loader with the reference's format ["type", value] (util/config.py:4-43)."""
+    import json
+    conv = dict(int=int, float=float, str=str, bool=lambda v: bool(int(v)), none=lambda v: None)
+    with open(path) as f:
+        raw = json.load(f)
+    out = {}
+    for k, (t, v) in raw.items():
+        out[k] = [conv[t](x) for x in v] if isinstance(v, list) else conv[t](v)
+    return out
+
+
+class SyntheticFaces(object):
+    """Stand-in for MultiLMDBDataset + PairLMDBDataset (util/lmdb_loader.py:12-237): `n_batches`
+    batches of uniform-uint8 images normalised as the loader does, instance labels uniform in
+    [0, num_class), pair ids drawn without replacement."""
+
+    def __init__(self, num_class, batch_size, n_batches, device, seed=0, image_size=112):
+        self.num_class, self.B, self.n, self.dev, self.hw = num_class, batch_size, n_batches, device, image_size
+        self.rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return self.n
+
+    def _images(self, n):
+        u8 = torch.from_numpy(self.rng.integers(0, 256, size=(n, 3, self.hw, self.hw), dtype=np.uint8))
+        return ((u8.to(self.dev, non_blocking=True).float() - 127.5) * 0.0078125)
+
+    def __iter__(self):
+        h = self.B // 2
+        for _ in range(self.n):
+            inst = self._images(self.B)                                            # instance batch (main.py:35)
+            inst_label = torch.from_numpy(self.rng.integers(0, self.num_class, size=self.B).astype(np.int64))
+            ids = torch.from_numpy(self.rng.choice(self.num_class, size=h, replace=False).astype(np.int64))
+            yield inst, inst_label, self._images(h), self._images(h), ids         # + id batch (main.py:43)
+
+
+def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_iter, lr_policy, lr_scheduler,
+                    max_epochs, world=1, log=print):
+    random.seed(cur_epoch)
+    db_size = len(data)
+    start = time.time()
+    loss = None
+    for batch_idx, (ins_images, instance_label, images1, images2, id_indexes) in enumerate(data):
+        if lr_policy != 'ReduceLROnPlateau':
+            lr_scheduler.update(None, batch_idx * 1.0 / db_size)                   # main.py:39-40
+        inst1, inst2 = torch.chunk(ins_images, 2)                                  # main.py:53-54
+        lab1, lab2 = torch.chunk(instance_label, 2)
+        optimizer.zero_grad()
+        x = torch.cat([images1, inst1])                                            # main.py:57-60
+        y = torch.cat([images2, inst2])
+        x_label = torch.cat([id_indexes, lab1])
+        y_label = torch.cat([id_indexes, lab2])
+        loss = step_model(x, y, x_label, y_label)                                  # main.py:65
+        loss.backward()
+        if world > 1:
+            step_model.reduce_gradients(optimizer)
+        optimizer.step()
+        real_iter += 1
+        if real_iter % conf.print_freq == 0:                                       # main.py:76-85
+            loss_val = loss.item()
+            lr = optimizer.param_groups[0]['lr']
+            log("epoch %d iter %d loss %.4f lr %.5f  %.1f it/s" % (cur_epoch, real_iter, loss_val, lr,
+                                                                   conf.print_freq / max(time.time() - start, 1e-9)))
+            if lr_policy == 'ReduceLROnPlateau':
+                lr_scheduler.step(loss_val)
+            start = time.time()
+            if conf.saved_dir and (world == 1 or torch.distributed.get_rank() == 0):
+                os.makedirs(conf.saved_dir, exist_ok=True)
+                torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict(),
+                            'fc': ffc_net.queue.cpu(), 'qp': ffc_net.queue_position_dict.to_dict()},
+                           os.path.join(conf.saved_dir, '%d.pt' % (real_iter // conf.print_freq)))
+    return real_iter, loss
+
+
+def train(conf, log=print):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    torch.manual_seed(0)
+    ffc_net = FFC(conf.net_type, conf.feat_dim, conf.queue_size, conf.scale, conf.loss_type, conf.margin, conf.alpha,
+                  conf.neg_margin, conf.pretrained_model_path, conf.num_class).cuda()          # main.py:116-117
+    optim_config = load_config(conf.optim_config) if conf.optim_config else dict(OPTIM_CONFIG)
+    optim, lr_scheduler = get_optim_scheduler([p for p in ffc_net.parameters() if p.requires_grad], optim_config)
+    step_model = ffc_net
+    if world > 1:
+        from .parallel import DataParallelFFC
+        step_model = DataParallelFFC(ffc_net, dist)
+    rank = dist.get_rank() if dist else 0
+    real_iter, loss = 0, None
+    for epoch in range(optim_config['epochs']):                                    # main.py:134-140
+        if optim_config['scheduler'] != 'ReduceLROnPlateau':
+            lr_scheduler.update(epoch, 0.0)
+        data = SyntheticFaces(conf.num_class, conf.batch_size, conf.iters_per_epoch, dev, seed=1000 * epoch + rank)
+        real_iter, loss = train_one_epoch(data, ffc_net, step_model, optim, epoch + 1, conf, real_iter,
+                                          optim_config['scheduler'], lr_scheduler, optim_config['epochs'], world, log)
+    return ffc_net, loss
+
+
+def parse_args(argv=None):
+    conf = argparse.ArgumentParser(description='fast face classification (MI355X path).')
+    conf.add_argument('--saved_dir', default='checkpoint', type=str)
+    conf.add_argument('--net_type', type=str, default='ir50')            # the reference's default 'r50' is out of scope
+    conf.add_argument('--queue_size', type=int, default=1000)
+    conf.add_argument('--print_freq', type=int, default=1000)
+    conf.add_argument('--pretrained_model_path', type=str, default='')
+    conf.add_argument('--batch_size', type=int, default=64)
+    conf.add_argument('--alpha', type=float, default=0.99)
+    conf.add_argument('--loss_type', type=str, default='Arc', choices=['Arc', 'AM', 'SV'])
+    conf.add_argument('--margin', type=float, default=0.5)
+    conf.add_argument('--scale', type=float, default=32.0)
+    conf.add_argument('--neg_margin', type=float, default=0.25)
+    conf.add_argument('--sync_bn', action='store_true', default=False)   # parsed and unused, as in the reference (:162)
+    conf.add_argument('--feat_dim', type=int, default=512)
+    conf.add_argument('--num_class', type=int, default=100000, help='identities of the synthetic dataset')
+    conf.add_argument('--iters_per_epoch', type=int, default=100)
+    conf.add_argument('--optim_config', type=str, default='', help='typed-JSON file in the format of config/optim_config')
+    return conf.parse_args(argv)
+
+
+if __name__ == '__main__':
+    train(parse_args())

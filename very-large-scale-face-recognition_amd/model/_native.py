@@ -1,0 +1,196 @@
+"""Shared machinery of the natively executed backbones (iResNet, MobileFaceNet): the torch.nn layers of
+a backbone are parameter containers only; forward / backward are single calls into the C++ executor
+(csrc/iresnet.cpp, csrc/mobilenet.cpp), which accumulates gradients straight into the parameters'
+.grad buffers."""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _BackboneFn(torch.autograd.Function):
+    """One node for the whole backbone: forward = vlsfr_iresnet_forward, backward =
+    vlsfr_iresnet_backward, which accumulates straight into the parameters' .grad buffers."""
+
+    @staticmethod
+    def forward(ctx, x, net, *params):
+        emb, ws = net._run_forward(x, save=True)
+        ctx.net, ctx.ws, ctx.B = net, ws, x.shape[0]
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        ctx.net._run_backward(demb.contiguous().float(), ctx.ws, ctx.B)
+        ctx.ws = None
+        return (None, None) + (None,) * len(ctx.net._plist)
+
+
+
+class NativeBackbone(nn.Module):
+    """Subclasses define `_cprefix` ("vlsfr_iresnet" / "vlsfr_mobilenet"), `_create_args()` (the
+    ctypes arguments of <prefix>_create before the batch size... see _handle) and the module tree."""
+    _cprefix = None
+    feat_dim = None
+    image_size = 112
+
+    def _init_native(self):
+        self._handles = {}
+        self._wcache = None
+        self._w_sig = None
+        self._scratch = None
+        self._eval_ctx = None
+        self._nbt_pending = 0
+        self.weights_dirty = True
+
+    def flush_counters(self):
+        """Adds the forward passes seen since the last flush to every BatchNorm's num_batches_tracked
+        (kept off the per-step path: the reference bumps one tiny tensor per BatchNorm per forward)."""
+        if self._nbt_pending:
+            for name, b in self.named_buffers():
+                if name.endswith("num_batches_tracked"):
+                    b += self._nbt_pending
+            self._nbt_pending = 0
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_counters()
+        return super(NativeBackbone, self).state_dict(*args, **kwargs)
+
+    def _create(self, L, B, h):
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------------------------------
+    @property
+    def _plist(self):
+        cache = self.__dict__.get("_plist_cache")
+        if cache is None:
+            cache = [p for _, p in self.named_parameters()]
+            self.__dict__["_plist_cache"] = cache
+        return cache
+
+    def _tables(self):
+        """Pointer tables in the executor's order (= registration order of the reference module)."""
+        params = self._plist
+        for p in params:
+            p._vlsfr_owner = self
+            if p.dim() == 4 and not p.data.permute(0, 2, 3, 1).is_contiguous():
+                p.data = p.data.contiguous(memory_format=torch.channels_last)   # e.g. after load_state_dict copies
+            elif p.dim() != 4 and not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+        running = []
+        for name, b in self.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                running.append(b)
+        return params, running
+
+    def _handle(self, B, device):
+        L = _lib.lib()
+        key = (B, str(device))
+        if key not in self._handles:
+            h = ctypes.c_void_p()
+            self._create(L, B, h)
+            for fn in ("_wcache_bytes", "_ctx_bytes", "_scratch_bytes"):
+                getattr(L, self._cprefix + fn).restype = ctypes.c_size_t
+                getattr(L, self._cprefix + fn).argtypes = [ctypes.c_void_p]
+            nump = getattr(L, self._cprefix + "_num_params")
+            nump.restype = ctypes.c_int32
+            nump.argtypes = [ctypes.c_void_p]
+            assert nump(h) == len(self._plist), (nump(h), len(self._plist))
+            sizes = tuple(getattr(L, self._cprefix + fn)(h) for fn in ("_wcache_bytes", "_ctx_bytes", "_scratch_bytes"))
+            self._handles[key] = (h, sizes)
+        return self._handles[key]
+
+    def _prepare(self, h, sizes, params, device):
+        """bf16 operand copies of the weights, refreshed only when the weights changed."""
+        L = _lib.lib()
+        sig = (tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
+        if self._wcache is None or self._wcache.numel() != sizes[0] or self._wcache.device != device:
+            self._wcache = torch.empty(sizes[0], dtype=torch.uint8, device=device)
+            self.weights_dirty = True
+        if self.weights_dirty or sig != self._w_sig:
+            fn = getattr(L, self._cprefix + "_prepare_weights")
+            fn.restype = ctypes.c_int
+            _lib.check(fn(h, _ptr_array(params), ctypes.c_void_p(self._wcache.data_ptr()), _stream()),
+                       self._cprefix + "_prepare_weights")
+            self._w_sig, self.weights_dirty = sig, False
+        if self._scratch is None or self._scratch.numel() < sizes[2] or self._scratch.device != device:
+            self._scratch = torch.empty(sizes[2], dtype=torch.uint8, device=device)
+
+    def _run_forward(self, x, save):
+        if not x.is_cuda:
+            raise _lib.VlsfrError("%s.forward needs a device tensor: the backbone has no CPU path" % type(self).__name__)
+        L = _lib.lib()
+        B = int(x.shape[0])
+        assert tuple(x.shape[1:]) == (3, self.image_size, self.image_size), x.shape
+        x = x.contiguous().float()
+        h, sizes = self._handle(B, x.device)
+        params, running = self._tables()
+        self._prepare(h, sizes, params, x.device)
+        if save:
+            ws = torch.empty(sizes[1], dtype=torch.uint8, device=x.device)
+        else:
+            if self._eval_ctx is None or self._eval_ctx.numel() < sizes[1] or self._eval_ctx.device != x.device:
+                self._eval_ctx = torch.empty(sizes[1], dtype=torch.uint8, device=x.device)
+            ws = self._eval_ctx
+        emb = torch.empty(B, self.feat_dim, dtype=torch.float32, device=x.device)
+        fwd = getattr(L, self._cprefix + "_forward")
+        fwd.restype = ctypes.c_int
+        run_tab = _ptr_array(running) if self.training else None
+        _lib.check(fwd(h, ctypes.c_void_p(x.data_ptr()), _ptr_array(params), run_tab,
+                       ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                       ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_void_p(emb.data_ptr()), _stream()),
+                   self._cprefix + "_forward")
+        if self.training:
+            self._nbt_pending += 1          # num_batches_tracked is materialised lazily (flush_counters)
+        self._keep = x
+        return emb, ws
+
+    def _run_backward(self, demb, ws, B):
+        L = _lib.lib()
+        h, sizes = self._handle(B, demb.device)
+        params, _ = self._tables()
+        grads = []
+        for p in params:
+            if not p.requires_grad:
+                grads.append(None)
+                continue
+            if p.grad is None:
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+            elif p.dim() == 4 and not p.grad.permute(0, 2, 3, 1).is_contiguous():
+                p.grad = p.grad.contiguous(memory_format=torch.channels_last)
+            grads.append(p.grad)
+        bwd = getattr(L, self._cprefix + "_backward")
+        bwd.restype = ctypes.c_int
+        _lib.check(bwd(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
+                       ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                       ctypes.c_void_p(self._scratch.data_ptr()), _stream()), self._cprefix + "_backward")
+
+    def forward(self, x):
+        # Training mode always (the reference never calls .eval(), ffc.py:22-23); eval() only stops
+        # the running-statistics update.
+        params = self._plist
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _BackboneFn.apply(x, self, *params)
+        return self._run_forward(x, save=False)[0]
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for h, _ in self._handles.values():
+                getattr(L, self._cprefix + "_destroy")(h)
+        except Exception:
+            pass
+
+

@@ -100,11 +100,33 @@ def bn_backward(dy, x, M, C, HW, mean, invstd, gamma, beta, slope=None, dx_add=N
     return dx
 
 
-def stem_im2col(x_nchw):
+def stem_im2col(x_nchw, stride=1):
     N, _, H, W = x_nchw.shape
-    out = torch.empty(N * H * W, 32, dtype=torch.bfloat16, device=x_nchw.device)
-    _call("vlsfr_stem_im2col", _p(x_nchw), _p(out), ctypes.c_int32(N), ctypes.c_int32(H), ctypes.c_int32(W), _st())
+    Ho, Wo = out_hw(H, 3, stride, 1), out_hw(W, 3, stride, 1)
+    out = torch.empty(N * Ho * Wo, 32, dtype=torch.bfloat16, device=x_nchw.device)
+    _call("vlsfr_stem_im2col", _p(x_nchw), _p(out), ctypes.c_int32(N), ctypes.c_int32(H), ctypes.c_int32(W),
+          ctypes.c_int32(stride), _st())
     return out
+
+
+def dwconv_fwd(x, w, desc, stats=None):
+    Ho, Wo = out_hw(desc.H, desc.R, desc.stride, desc.pad), out_hw(desc.W, desc.S, desc.stride, desc.pad)
+    y = torch.empty(desc.N, Ho, Wo, desc.Cout, dtype=torch.bfloat16, device=x.device)
+    _call("vlsfr_dwconv_fwd", ctypes.byref(desc), _p(x), _p(w), _p(y), _p(stats), _st())
+    return y
+
+
+def dwconv_dgrad(dy, w, desc):
+    dx = torch.empty(desc.N, desc.H, desc.W, desc.Cin, dtype=torch.bfloat16, device=dy.device)
+    _call("vlsfr_dwconv_dgrad", ctypes.byref(desc), _p(dy), _p(w), _p(dx), _st())
+    return dx
+
+
+def dwconv_wgrad(dy, x, desc, dw=None):
+    if dw is None:
+        dw = torch.zeros(desc.Cout, desc.R * desc.S, dtype=torch.float32, device=x.device)
+    _call("vlsfr_dwconv_wgrad", ctypes.byref(desc), _p(dy), _p(x), _p(dw), _st())
+    return dw
 
 
 def embed_fwd(fc, fc_bias, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
@@ -117,11 +139,11 @@ def embed_fwd(fc, fc_bias, gamma, beta, running_mean=None, running_var=None, eps
     return emb, (z, xhat, invstd, inv_norm)
 
 
-def embed_bwd(demb, emb, saved, gamma, dbeta, dfc_bias):
+def embed_bwd(demb, emb, saved, gamma, dbeta, dfc_bias, dgamma=None):
     z, xhat, invstd, inv_norm = saved
     B, D = emb.shape
     dz = torch.empty(B, D, dtype=torch.float32, device=emb.device)
     dfc = torch.empty(B, D, dtype=torch.bfloat16, device=emb.device)
     _call("vlsfr_embed_bwd", _p(demb), _p(emb), _p(inv_norm), _p(xhat), _p(invstd), _p(gamma), _p(dz), _p(dfc),
-          _p(dbeta), _p(dfc_bias), ctypes.c_int32(B), ctypes.c_int32(D), _st())
+          _p(dbeta), _p(dfc_bias), _p(dgamma), ctypes.c_int32(B), ctypes.c_int32(D), _st())
     return dfc
