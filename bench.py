@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-glds", type=int, default=-1, help="A/B switch for the conv kernel variant (vlsfr_set_option)")
+    ap.add_argument("--pool", default="sharded", choices=["sharded", "replicated"],
+                    help="N > 1: identity-sharded pool (softmax all-reduce) or replicated pool")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the "
                     "multi-process path on a 1-GPU box")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -137,7 +139,7 @@ def main():
     from vlsfr_amd import _lib
     from vlsfr_amd.ffc import FFC
     from vlsfr_amd.optim import get_optim_scheduler
-    from vlsfr_amd.parallel import DataParallelFFC
+    from vlsfr_amd.parallel import DataParallelFFC, ShardedFFC
 
     Q = args.queue or args.identities
     torch.manual_seed(1234)                                   # identical initial weights on every rank
@@ -148,7 +150,10 @@ def main():
                milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])     # config/optim_config
     opt, sched = get_optim_scheduler([p for p in model.parameters() if p.requires_grad], cfg)
     sched.update(0, 0.0)
-    step_model = DataParallelFFC(model, dist) if world > 1 else model
+    step_model = model
+    if world > 1:
+        sharded = args.pool == "sharded" and Q % world == 0 and args.loss != "SV"
+        step_model = ShardedFFC(model, dist) if sharded else DataParallelFFC(model, dist)
     rng = np.random.default_rng(1234 + rank)
     B = args.batch
     batches = [synth_batch(rng, B, args.identities, dev) for _ in range(min(4, args.steps + args.warmup))]
@@ -218,7 +223,7 @@ def main():
         "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
                                "(2 x %d faces per step per GPU), SGD-nesterov, 112x112 synthetic images" %
                                (args.net, args.identities, Q, args.feat, args.loss, B, B),
-                   "parallelism": "dp%d" % world, "loss": float(loss.detach())},
+                   "parallelism": ("dp%d" % world) + ("" if world == 1 else "+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")), "loss": float(loss.detach())},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

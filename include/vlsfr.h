@@ -113,9 +113,11 @@ int vlsfr_dcp_undo(vlsfr_lru* h, uint8_t* qp, const int32_t* undo_slot, const ui
  *    restore of ffc.py:240-241,255 are not needed: the rollback pass never mutates the pool).
  *    queue: fp32 [2, Q, D] row-major; duplicate (row, col): the highest batch index wins.
  * ---------------------------------------------------------------------------------------- */
+/* cols are global slot ids; with an identity-sharded pool (queue holds slots
+ * [slot_lo, slot_lo + Q)) writes to slots of other ranks are skipped */
 int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g /*[n, D]*/,
                        const int32_t* rows /*[n] dev*/, const int32_t* cols /*[n] dev*/, int32_t n,
-                       void* stream);
+                       int32_t slot_lo, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Fused DCP head (device): loss and dL/dp of one FFC pass in one sweep over queue[0].
@@ -139,12 +141,30 @@ typedef struct vlsfr_head_cfg {
   int32_t hard_neg;
   int32_t precise;
   int32_t n_chunks;
+  int32_t slot_lo;        /* identity-sharded pool: queue holds global slots [slot_lo, slot_lo + Q); else 0 */
   int32_t n_rows_total;   /* 0 or B: single process.  > B: this call holds B probe rows of a batch of
                              n_rows_total rows spread over ranks (g, the special table, n_pos and the
                              loss normalisers refer to the whole batch; pool_label to these B rows) */
 } vlsfr_head_cfg;
 
 size_t vlsfr_head_workspace_bytes(const vlsfr_head_cfg* cfg);
+/* Identity-sharded pool (the class matrix split by slot range over the ranks of a node): this rank's
+ * partial softmax state of one pass for ALL B rows of the (all-gathered) batch over its own slots —
+ * per row and variant M (log2 units), L, O[D] (unnormalised), the target terms T[D] / zt if it owns
+ * the label slot, and its local top-k hard-negative candidates (value, global slot).  The ranks
+ * combine with all-reduce(max) on M and all-reduce(sum) on the rescaled (O, T, L, zt)
+ * (head.py ShardedDcpHead).  AM / Arc only. */
+int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                             const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                             const int32_t* src2, int32_t n_special, int32_t n_pos, float* out_M /*[B,2]*/,
+                             float* out_L /*[B,2]*/, float* out_zt /*[B,2]*/, float* out_O /*[B,2,D]*/,
+                             float* out_T /*[B,2,D]*/, float* cand_val /*[B,2,10]*/, int32_t* cand_col /*[B,2,10]*/,
+                             void* workspace, size_t workspace_bytes, void* stream);
+/* T[row, v, :] += sel_w * class vector for the globally selected hard negatives this rank owns */
+int vlsfr_head_outlier_accum(const vlsfr_head_cfg* cfg, const float* g, const float* queue,
+                             const int32_t* special_col, const int32_t* src1, const int32_t* src2,
+                             int32_t n_special, const int32_t* sel_col /*[B,2,k]*/, const float* sel_w /*[B,2,k]*/,
+                             int32_t k, float* T /*[B,2,D]*/, void* stream);
 int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
                        const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
                        const int32_t* src2, int32_t n_special, int32_t n_pos, float* loss_out, float* dP,

@@ -200,3 +200,82 @@ def test_head_row_sharded_equals_full_batch(loss_type, margin):
         assert head.lru.state_dict() == full.lru.state_dict()
         assert head.qp.tolist() == full.qp.tolist()
         assert torch.equal(head.queue, full.queue)
+
+
+class _SimComm(object):
+    """In-process stand-in for the three collectives of the sharded head: the simulated ranks run
+    phase by phase, and each collective is evaluated over the list of all ranks' tensors."""
+
+    def __init__(self, world):
+        self.world, self.bufs = world, {}
+
+    def run(self, name, tensors):
+        if name == "max":
+            out = torch.stack(tensors).max(0).values
+        elif name == "sum":
+            out = torch.stack(tensors).sum(0)
+        else:
+            out = torch.stack(tensors)
+        return [out.clone() for _ in tensors]
+
+
+def _sharded_pass(shards, p, g, pl, gl, trans):
+    """Drives `world` simulated ranks through partial -> combine -> finish in lockstep."""
+    world = len(shards)
+    sts = [h.partial(p, g, pl, gl, trans) for h in shards]
+    sim = _SimComm(world)
+
+    class Comm(object):            # replays one rank's combine() against pre-computed collective results
+        def __init__(self, r):
+            self.r, self.step = r, 0
+
+        def all_reduce_max(self, t):
+            return torch.stack([s["M"] for s in sts]).max(0).values
+
+        def all_gather(self, t):
+            key = "cand_val" if t.dtype == torch.float32 else "cand_col"
+            return torch.stack([s[key] for s in sts])
+
+        def all_reduce_sum(self, t):
+            self.mine = t
+            return None
+    comms = [Comm(r) for r in range(world)]
+    for r, h in enumerate(shards):           # first: everything up to the sum-reduce (needs all ranks' packed)
+        h.combine(sts[r], comms[r])
+    total = torch.stack([c.mine for c in comms]).sum(0)
+    outs = []
+    for r, h in enumerate(shards):
+        sts[r]["packed"] = total.clone()
+        outs.append(h.finish(sts[r]))
+    return outs
+
+
+@pytest.mark.parametrize("loss_type,margin,n_id", [("Arc", 0.5, 1500), ("AM", 0.4, 6000)])
+@pytest.mark.parametrize("world", [2, 4])
+def test_identity_sharded_head_equals_single_pool(loss_type, margin, n_id, world):
+    """The identity-sharded pool (each rank owns Q / world slots, softmax state combined with
+    all-reduce(max) / all-reduce(sum)) reproduces the single-pool head: loss, dL/dp for every row,
+    pool contents, LRU and queue_position state — including evictions and outlier rows (n_id > Q)."""
+    from vlsfr_amd.head import DcpHead, ShardedDcpHead
+    Q, D, B, T = 2048, 128, 40, 3
+    case = common.head_case(777 + world, Q, D, B, T, n_id)
+    full = make_head(case["queue0"], loss_type, 32.0, margin, True)
+    q0 = torch.from_numpy(case["queue0"]).cuda()
+    Qs = Q // world
+    shards = [ShardedDcpHead(q0[:, r * Qs:(r + 1) * Qs].contiguous(), r, world, Q, 32.0, margin, loss_type, precise=True)
+              for r in range(world)]
+    for t in range(T):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            g = torch.from_numpy(case["G"][t, s]).cuda()
+            p = torch.from_numpy(case["P"][t, s]).cuda().requires_grad_(True)
+            loss = full.run_pass(p, g, pl, gl, trans)
+            loss.backward()
+            outs = _sharded_pass(shards, p.detach(), g, pl, gl, trans)
+            for l, dP in outs:
+                np.testing.assert_allclose(float(l), float(loss.detach()), rtol=2e-5, atol=1e-5)
+                np.testing.assert_allclose(dP.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    whole = torch.cat([h.queue for h in shards], dim=1)
+    assert torch.equal(whole, full.queue)
+    for h in shards:
+        assert h.lru.state_dict() == full.lru.state_dict() and h.qp.tolist() == full.qp.tolist()

@@ -434,7 +434,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
   for (int it = 0; it < nk; ++it) {
     // tiles issued after tile `it` may stay in flight: min(NST - 2, nk - 1 - it) of them, (AI + BI) DMAs each
     const int later = (nk - 1 - it) < (NST - 2) ? (nk - 1 - it) : (NST - 2);
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
+    if (later >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (AI + BI)) : "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -706,6 +707,7 @@ int run_igemm(ConvArgs a, hipStream_t st) {
     const bool big = a.Mrows >= 128;
     if (g_use_glds == 1) rc = big ? launch_igemm_glds<128, 128, 64, 4>(a, P, st) : launch_igemm_glds<64, 128, 64, 4>(a, P, st);
     else if (g_use_glds == 2) rc = big ? launch_igemm_glds<128, 128, 32, 4>(a, P, st) : launch_igemm_glds<64, 128, 32, 4>(a, P, st);
+    else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
     else rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     if (rc != VLSFR_OK) return rc;
   } else if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);

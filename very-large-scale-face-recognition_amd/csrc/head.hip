@@ -53,6 +53,7 @@ struct SweepArgs {
   int32_t* topk_idx;
   int32_t Bp;
   int32_t n_rowblk;
+  int32_t slot_lo;       // global slot id of local slot 0 (identity-sharded pool); 0 otherwise
 };
 
 template <int DP>
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256, 1) void head_sweep_kernel(SweepArgs a) {
   for (int i = tid; i < nwords; i += 256) bits[i] = 0u;
   __syncthreads();
   for (int i = tid; i < a.n_special; i += 256) {
-    int64_t c = a.special_col[i];
+    int64_t c = (int64_t)a.special_col[i] - a.slot_lo;   // special columns carry global slot ids
     if (c >= c0 && c < c1) atomicOr(&bits[(c - c0) >> 5], 1u << ((c - c0) & 31));
   }
 
@@ -360,6 +361,7 @@ struct SpecialArgs {
   const int32_t* src2;
   float* cos1;          // [B, n_special]
   float* cos2;
+  int32_t slot_lo;      // identity-sharded pool: this rank owns global slots [slot_lo, slot_lo + Q)
 };
 
 __device__ __forceinline__ const float* special_vec(const float* g, const float* queue, int64_t Q, int D, int col,
@@ -371,7 +373,8 @@ __device__ __forceinline__ const float* special_vec(const float* g, const float*
 
 __global__ __launch_bounds__(256) void head_special_kernel(SpecialArgs a) {
   const int s = blockIdx.x;
-  const int col = a.special_col[s];
+  const int col = a.special_col[s] - a.slot_lo;
+  if (col < 0 || col >= a.Q) return;   // owned by another rank
   const int s1 = a.src1[s], s2 = a.src2[s];
   const float* v1 = special_vec(a.g, a.queue, a.Q, a.D, col, s1);
   const float* v2 = special_vec(a.g, a.queue, a.Q, a.D, col, s2);
@@ -627,6 +630,225 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
   for (int d = tid; d < D; d += 256) a.dP[(size_t)i * D + d] = dp[d];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Identity-sharded pool: every rank sweeps its own slots for ALL rows of the batch and
+// emits per row and variant a partial softmax state relative to its local maximum:
+//   M (log2 units), L = sum 2^(zz - M), O[D] = sum 2^(zz - M) * dlogit/dcos * w   (unnormalised),
+//   T[D] = -scale/n_pos * dtm * w_target and zt = scale * tm if this rank owns the target slot,
+//   and for outlier rows its local top-k (value, global slot).
+// The ranks then all-reduce max(M), rescale, and sum (O, T, L, zt); see head.py ShardedDcpHead.
+// ------------------------------------------------------------------------------------------------
+struct ShardFinishArgs {
+  FinishArgs f;
+  int32_t slot_lo;
+  float* out_M;        // [B, 2]
+  float* out_L;        // [B, 2]
+  float* out_zt;       // [B, 2]
+  float* out_O;        // [B, 2, D]
+  float* out_T;        // [B, 2, D]
+  float* cand_val;     // [B, 2, KTOP]
+  int32_t* cand_col;   // [B, 2, KTOP] global slot ids (-1 = none)
+};
+
+__global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs sa) {
+  const FinishArgs& a = sa.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int D = a.D;
+  float* red = (float*)smem;                    // [16]
+  float* wts = red + 16;                        // [max(n_chunks, n_special)]
+  const int label = a.pool_label[i];
+  const float qs = a.scale * LOG2E;
+  const int lo = sa.slot_lo, hi = sa.slot_lo + (int)a.Q;
+  __shared__ int sh_idx[1];
+  auto owned = [&](int s) { const int c = a.special_col[s]; return c >= lo && c < hi; };
+  auto block_max = [&](float v) -> float {
+    v = wave_max(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return r;
+  };
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+  };
+  if (label >= 0) {
+    if (tid == 0) sh_idx[0] = -1;
+    __syncthreads();
+    for (int s = tid; s < a.n_special; s += 256)
+      if (a.special_col[s] == label) sh_idx[0] = s;
+    __syncthreads();
+    const int st_all = sh_idx[0];
+    const int st = (st_all >= 0 && label >= lo && label < hi) ? st_all : -1;   // target owned by this rank?
+    __syncthreads();
+    const float inv_pos = 1.f / (float)a.n_pos;
+    for (int v = 0; v < 2; ++v) {
+      const float* cs = (v == 0 ? a.cos1 : a.cos2) + (size_t)i * a.n_special;
+      const int32_t* src = (v == 0 ? a.src1 : a.src2);
+      float tm = 0.f, dtm = 0.f;
+      if (st >= 0) {
+        const float gt = cs[st];
+        if (a.loss_type == 0) {
+          tm = gt - a.margin;
+          dtm = 1.f;
+        } else {
+          const float sn = sqrtf(1.f - gt * gt);
+          tm = gt * cosf(a.margin) - sn * sinf(a.margin);
+          dtm = cosf(a.margin) + gt / sn * sinf(a.margin);
+        }
+      }
+      float mx = NEG_BIG;
+      for (int c = tid; c < a.n_chunks; c += 256) mx = fmaxf(mx, a.part_m[v][(size_t)c * a.Bp + i]);
+      for (int s = tid; s < a.n_special; s += 256)
+        if (owned(s)) mx = fmaxf(mx, (s == st ? tm : cs[s]) * qs);
+      const float M = block_max(mx);
+      float lsum = 0.f;
+      for (int c = tid; c < a.n_chunks; c += 256) {
+        const float w = exp2f(a.part_m[v][(size_t)c * a.Bp + i] - M);
+        wts[c] = w;
+        lsum += w * a.part_l[v][(size_t)c * a.Bp + i];
+      }
+      for (int s = tid; s < a.n_special; s += 256)
+        if (owned(s)) lsum += exp2f((s == st ? tm : cs[s]) * qs - M);
+      const float L = block_sum(lsum);
+      float* O = sa.out_O + ((size_t)i * 2 + v) * D;
+      float* T = sa.out_T + ((size_t)i * 2 + v) * D;
+      for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int c = 0; c < a.n_chunks; ++c) acc += wts[c] * a.part_o[v][((size_t)c * a.Bp + i) * a.DP + d];
+        O[d] = acc;
+        T[d] = 0.f;
+      }
+      __syncthreads();
+      for (int s = tid; s < a.n_special; s += 256)
+        wts[s] = owned(s) ? exp2f((s == st ? tm : cs[s]) * qs - M) * (s == st ? dtm : 1.f) : 0.f;
+      __syncthreads();
+      for (int s = 0; s < a.n_special; ++s) {
+        const float w = wts[s];
+        if (w == 0.f) continue;
+        const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[s] - lo, src[s]);
+        for (int d = tid; d < D; d += 256) O[d] += w * vec[d];
+      }
+      if (st >= 0) {
+        const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[st] - lo, src[st]);
+        const float k = -a.scale * inv_pos * dtm;
+        for (int d = tid; d < D; d += 256) T[d] = k * vec[d];
+      }
+      if (tid == 0) {
+        sa.out_M[i * 2 + v] = M;
+        sa.out_L[i * 2 + v] = L;
+        sa.out_zt[i * 2 + v] = st >= 0 ? tm * a.scale : 0.f;
+      }
+      __syncthreads();
+    }
+    for (int e = tid; e < 2 * KTOP; e += 256) {
+      sa.cand_val[(size_t)i * 2 * KTOP + e] = NEG_BIG;
+      sa.cand_col[(size_t)i * 2 * KTOP + e] = -1;
+    }
+  } else {
+    // outlier row: local top-k candidates (raw cosines) per variant; no softmax state
+    const size_t ncand_sweep = (size_t)a.n_chunks * 4 * KTOP;
+    for (int v = 0; v < 2; ++v) {
+      const float* cs = (v == 0 ? a.cos1 : a.cos2) + (size_t)i * a.n_special;
+      float last_v = 3.0e38f;
+      long long last_k = -1;
+      for (int k = 0; k < KTOP; ++k) {
+        float bv = NEG_BIG;
+        long long bk = 0x7fffffffffffffffLL;
+        auto consider = [&](float cv, long long key) {
+          if (cv <= NEG_BIG) return;
+          const bool after = (cv < last_v) || (cv == last_v && key > last_k);
+          if (!after) return;
+          if (cv > bv || (cv == bv && key < bk)) {
+            bv = cv;
+            bk = key;
+          }
+        };
+        for (size_t c = tid; c < ncand_sweep; c += 256) {
+          const size_t chunk = c / (4 * KTOP), rest = c % (4 * KTOP);
+          const size_t off = ((chunk * a.Bp + i) * 4) * KTOP + rest;
+          if (a.topk_idx[off] >= 0) consider(a.topk_val[off], (long long)a.topk_idx[off] + lo);
+        }
+        for (int s = tid; s < a.n_special; s += 256)
+          if (owned(s)) consider(cs[s], (long long)a.special_col[s]);
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(bv, o, 64);
+          const long long ok = __shfl_xor(bk, o, 64);
+          if (ov > bv || (ov == bv && ok < bk)) {
+            bv = ov;
+            bk = ok;
+          }
+        }
+        __shared__ float wv[4];
+        __shared__ long long wk[4];
+        if (lane == 0) {
+          wv[wave] = bv;
+          wk[wave] = bk;
+        }
+        __syncthreads();
+        bv = wv[0];
+        bk = wk[0];
+        for (int w = 1; w < 4; ++w)
+          if (wv[w] > bv || (wv[w] == bv && wk[w] < bk)) {
+            bv = wv[w];
+            bk = wk[w];
+          }
+        __syncthreads();
+        if (tid == 0) {
+          sa.cand_val[((size_t)i * 2 + v) * KTOP + k] = bv;
+          sa.cand_col[((size_t)i * 2 + v) * KTOP + k] = bv > NEG_BIG ? (int32_t)bk : -1;
+        }
+        if (bv > NEG_BIG) {
+          last_v = bv;
+          last_k = bk;
+        } else {
+          last_v = NEG_BIG;   // exhausted: the remaining entries stay empty
+        }
+      }
+      for (int d = tid; d < D; d += 256) {
+        sa.out_O[((size_t)i * 2 + v) * D + d] = 0.f;
+        sa.out_T[((size_t)i * 2 + v) * D + d] = 0.f;
+      }
+      if (tid == 0) {
+        sa.out_M[i * 2 + v] = NEG_BIG;
+        sa.out_L[i * 2 + v] = 0.f;
+        sa.out_zt[i * 2 + v] = 0.f;
+      }
+    }
+  }
+}
+
+// T[row, v, :] += weight * class vector of the globally selected hard negatives this rank owns
+// sel_col: [B, 2, k] global slot ids (or -1), sel_w: [B, 2, k] weights (0 for clipped / empty entries)
+__global__ __launch_bounds__(256) void head_outlier_accum_kernel(const float* g, const float* queue, int64_t Q, int D,
+                                                                 int slot_lo, const int32_t* special_col,
+                                                                 const int32_t* src1, const int32_t* src2,
+                                                                 int n_special, const int32_t* sel_col,
+                                                                 const float* sel_w, int k, float* T) {
+  const int row = blockIdx.x, v = blockIdx.y;
+  for (int e = 0; e < k; ++e) {
+    const int col = sel_col[((size_t)row * 2 + v) * k + e];
+    const float w = sel_w[((size_t)row * 2 + v) * k + e];
+    if (col < slot_lo || col >= slot_lo + (int)Q || w == 0.f) continue;
+    int src = -1;   // swept columns read queue[0]; special columns follow their variant's source
+    for (int s = 0; s < n_special; ++s)
+      if (special_col[s] == col) {
+        src = (v == 0 ? src1 : src2)[s];
+        break;
+      }
+    const float* vec = special_vec(g, queue, Q, D, col - slot_lo, src);
+    for (int d = threadIdx.x; d < D; d += 256) T[((size_t)row * 2 + v) * D + d] += w * vec[d];
+  }
+}
+
 __global__ void head_loss_reduce_kernel(const float* row_loss, int n, float* out) {
   // fixed-order sum: the scalar loss is bitwise reproducible run to run
   __shared__ float sh[256];
@@ -643,14 +865,16 @@ __global__ void head_loss_reduce_kernel(const float* row_loss, int n, float* out
 
 // queue[rows[i], cols[i]] = g[i]; duplicates resolved "highest batch index wins"
 __global__ __launch_bounds__(256) void pool_scatter_kernel(float* queue, int64_t Q, int D, const float* g,
-                                                           const int32_t* rows, const int32_t* cols, int n) {
+                                                           const int32_t* rows, const int32_t* cols, int n,
+                                                           int slot_lo) {
   const int i = blockIdx.x;
-  const int r = rows[i], c = cols[i];
+  const int r = rows[i], c = cols[i] - slot_lo;
+  if (c < 0 || c >= Q) return;   // slot owned by another rank (identity-sharded pool)
   __shared__ int dead;
   if (threadIdx.x == 0) dead = 0;
   __syncthreads();
   for (int j = i + 1 + threadIdx.x; j < n; j += 256)
-    if (rows[j] == r && cols[j] == c) dead = 1;
+    if (rows[j] == r && cols[j] - slot_lo == c) dead = 1;
   __syncthreads();
   if (dead) return;
   float* dst = queue + ((size_t)r * Q + c) * D;
@@ -748,11 +972,11 @@ int dispatch_sweep(int DP, const SweepArgs& a, bool topk, bool sv, dim3 grid, hi
 extern "C" {
 
 int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g, const int32_t* rows, const int32_t* cols,
-                       int32_t n, void* stream) {
+                       int32_t n, int32_t slot_lo, void* stream) {
   if (!queue || !g || !rows || !cols || Q <= 0 || D <= 0 || n < 0)
     return fail(VLSFR_EINVAL, "vlsfr_pool_scatter: bad argument");
   if (n == 0) return VLSFR_OK;
-  hipLaunchKernelGGL(pool_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, queue, Q, D, g, rows, cols, n);
+  hipLaunchKernelGGL(pool_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, queue, Q, D, g, rows, cols, n, slot_lo);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_pool_scatter launch");
   return VLSFR_OK;
 }
@@ -789,7 +1013,7 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   const size_t rowsz = (size_t)pl.n_chunks * pl.Bp;
 
   if (n_special > 0) {
-    SpecialArgs sa{p, g, queue, cfg->Q, B, D, n_special, special_col, src1, src2, cos1, cos2};
+    SpecialArgs sa{p, g, queue, cfg->Q, B, D, n_special, special_col, src1, src2, cos1, cos2, cfg->slot_lo};
     hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
     VLSFR_HIP_CHECK_LAUNCH("head_special launch");
   }
@@ -816,6 +1040,7 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   a.topk_idx = (int32_t*)(ws + pl.off_ti);
   a.Bp = pl.Bp;
   a.n_rowblk = pl.n_rowblk;
+  a.slot_lo = cfg->slot_lo;
   const dim3 grid(pl.n_chunks * pl.n_rowblk);
   for (int set = 0; set < pl.n_sets; ++set) {
     a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
@@ -866,6 +1091,116 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   VLSFR_HIP_CHECK_LAUNCH("head_finish launch");
   hipLaunchKernelGGL(head_loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, 2 * B, loss_out);
   VLSFR_HIP_CHECK_LAUNCH("head_loss_reduce launch");
+  return VLSFR_OK;
+}
+
+int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                             const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                             const int32_t* src2, int32_t n_special, int32_t n_pos, float* out_M, float* out_L,
+                             float* out_zt, float* out_O, float* out_T, float* cand_val, int32_t* cand_col,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  Plan pl;
+  int rc = make_plan(cfg, &pl);
+  if (rc != VLSFR_OK) return rc;
+  if (!p || !g || !queue || !pool_label || !out_M || !out_L || !out_zt || !out_O || !out_T || !cand_val || !cand_col ||
+      !workspace)
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: null argument");
+  if (cfg->loss_type == 2) return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: SV is not covered by the sharded head yet");
+  const int B = cfg->B, D = cfg->D;
+  if (n_special < 0 || n_special > 3 * B || (n_special > 0 && (!special_col || !src1 || !src2)))
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: bad special-column table");
+  if (workspace_bytes < pl.total) return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* cos1 = (float*)(ws + pl.off_cos1);
+  float* cos2 = (float*)(ws + pl.off_cos2);
+  if (n_special > 0) {
+    SpecialArgs sa{p, g, queue, cfg->Q, B, D, n_special, special_col, src1, src2, cos1, cos2, cfg->slot_lo};
+    hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
+    VLSFR_HIP_CHECK_LAUNCH("head_special launch");
+  }
+  SweepArgs a;
+  a.p = p;
+  a.w0 = queue;
+  a.Q = cfg->Q;
+  a.B = B;
+  a.D = D;
+  a.chunk_cols = pl.chunk_cols;
+  a.n_chunks = pl.n_chunks;
+  a.special_col = special_col;
+  a.n_special = n_special;
+  a.pool_label = pool_label;
+  a.qscale = cfg->scale * LOG2E;
+  a.sv_t = 1.2f;
+  a.sv_thr = nullptr;
+  a.part_m = (float*)(ws + pl.off_m);
+  a.part_l = (float*)(ws + pl.off_l);
+  a.part_o = (float*)(ws + pl.off_o);
+  a.topk_val = (float*)(ws + pl.off_tv);
+  a.topk_idx = (int32_t*)(ws + pl.off_ti);
+  a.Bp = pl.Bp;
+  a.n_rowblk = pl.n_rowblk;
+  a.slot_lo = cfg->slot_lo;
+  const bool topk = n_pos < B;
+  const dim3 grid(pl.n_chunks * pl.n_rowblk);
+  rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, false, grid, st)
+                    : dispatch_sweep<false>(pl.DP, a, topk, false, grid, st);
+  if (rc != VLSFR_OK) return rc;
+  ShardFinishArgs sf;
+  FinishArgs& f = sf.f;
+  f.g = g;
+  f.queue = queue;
+  f.Q = cfg->Q;
+  f.B = B;
+  f.D = D;
+  f.DP = pl.DP;
+  f.Bp = pl.Bp;
+  f.n_chunks = pl.n_chunks;
+  f.n_special = n_special;
+  f.pool_label = pool_label;
+  f.special_col = special_col;
+  f.src1 = src1;
+  f.src2 = src2;
+  f.cos1 = cos1;
+  f.cos2 = cos2;
+  for (int v = 0; v < 2; ++v) {
+    f.part_m[v] = a.part_m;
+    f.part_l[v] = a.part_l;
+    f.part_o[v] = a.part_o;
+  }
+  f.topk_val = a.topk_val;
+  f.topk_idx = a.topk_idx;
+  f.loss_type = cfg->loss_type;
+  f.scale = cfg->scale;
+  f.margin = cfg->margin;
+  f.sv_t = 1.2f;
+  f.hard_neg = cfg->hard_neg;
+  f.n_pos = n_pos;
+  f.n_out = B - n_pos;
+  f.row_loss = nullptr;
+  f.dP = nullptr;
+  sf.slot_lo = cfg->slot_lo;
+  sf.out_M = out_M;
+  sf.out_L = out_L;
+  sf.out_zt = out_zt;
+  sf.out_O = out_O;
+  sf.out_T = out_T;
+  sf.cand_val = cand_val;
+  sf.cand_col = cand_col;
+  const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
+  hipLaunchKernelGGL(head_finish_shard_kernel, dim3(B), dim3(256), (size_t)(16 + nw) * 4, st, sf);
+  VLSFR_HIP_CHECK_LAUNCH("head_finish_shard launch");
+  return VLSFR_OK;
+}
+
+int vlsfr_head_outlier_accum(const vlsfr_head_cfg* cfg, const float* g, const float* queue, const int32_t* special_col,
+                             const int32_t* src1, const int32_t* src2, int32_t n_special, const int32_t* sel_col,
+                             const float* sel_w, int32_t k, float* T, void* stream) {
+  if (!cfg || !g || !queue || !sel_col || !sel_w || !T || k < 1 || k > KTOP)
+    return fail(VLSFR_EINVAL, "vlsfr_head_outlier_accum: bad argument");
+  hipLaunchKernelGGL(head_outlier_accum_kernel, dim3(cfg->B, 2), dim3(256), 0, (hipStream_t)stream, g, queue, cfg->Q,
+                     cfg->D, cfg->slot_lo, special_col, src1, src2, n_special, sel_col, sel_w, k, T);
+  VLSFR_HIP_CHECK_LAUNCH("head_outlier_accum launch");
   return VLSFR_OK;
 }
 

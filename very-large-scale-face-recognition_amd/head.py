@@ -21,7 +21,7 @@ class HeadCfg(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("D", ctypes.c_int32), ("Q", ctypes.c_int64),
                 ("loss_type", ctypes.c_int32), ("scale", ctypes.c_float), ("margin", ctypes.c_float),
                 ("hard_neg", ctypes.c_int32), ("precise", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
-                ("n_rows_total", ctypes.c_int32)]
+                ("slot_lo", ctypes.c_int32), ("n_rows_total", ctypes.c_int32)]
 
 
 def _stream_ptr():
@@ -93,7 +93,7 @@ class DcpHead(object):
     # -------------------------------------------------------------------------------------------
     def _cfg(self, B, B_total=0):
         return HeadCfg(B, self.D, self.Q, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), self.n_chunks, B_total)
+                       int(self.precise), self.n_chunks, 0, B_total)
 
     def _workspace(self, cfg, device):
         key = (cfg.B, cfg.n_rows_total, str(device))
@@ -172,7 +172,129 @@ class DcpHead(object):
             sc = self.L.vlsfr_pool_scatter
             sc.restype = ctypes.c_int
             rc = sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Q), ctypes.c_int32(self.D),
-                    ctypes.c_void_p(gd.data_ptr()), at(10), at(11), ctypes.c_int32(n), _stream_ptr())   # ffc.py:182
+                    ctypes.c_void_p(gd.data_ptr()), at(10), at(11), ctypes.c_int32(n), ctypes.c_int32(0), _stream_ptr())   # ffc.py:182
             _lib.check(rc, "vlsfr_pool_scatter")
         self._keep = (tab_d, pd, gd)     # keep operands alive until the next pass is enqueued
         return _HeadFn.apply(p, loss.reshape(()), dP)
+
+
+class ShardedDcpHead(object):
+    """Identity-sharded Dynamic Class Pool: rank `rank` of `world` holds pool slots
+    [rank * Qs, (rank + 1) * Qs) of the reference's queue[2, Q, D]; LRU / queue_position state is
+    replicated (every rank replays the global label sequence).  One pass =
+      partial()  — local sweep over the shard for ALL rows of the all-gathered batch
+      combine()  — all-reduce(max) of the row maxima, all-gather of the hard-negative candidates,
+                   rescale, all-reduce(sum) of (O, T, L, zt)          [3 small collectives]
+      finish()   — loss and dL/dp rows from the combined state; the committing pass scatters g
+                   into the owned slots.
+    The collectives are passed in (`comm`), so the same code runs under torch.distributed (RCCL) and
+    under the in-process simulator the single-GPU tests use."""
+
+    def __init__(self, queue_shard, rank, world, Q_total, scale, margin, loss_type, precise=False, lru=None, qp=None):
+        if loss_type == "SV":
+            raise _lib.VlsfrError("the identity-sharded head covers AM / Arc (SV needs a per-variant threshold exchange)")
+        self.L = _lib.lib()
+        self.queue = queue_shard                 # [2, Qs, D] fp32 device
+        self.rank, self.world = rank, world
+        self.Qs, self.D, self.Q = int(queue_shard.shape[1]), int(queue_shard.shape[2]), int(Q_total)
+        assert self.Qs * world == self.Q
+        self.slot_lo = rank * self.Qs
+        self.scale, self.margin, self.loss_type, self.precise = float(scale), float(margin), loss_type, bool(precise)
+        self.hard_neg = min(max(int(self.Q * 0.0002), 3), 10)
+        self.lru = lru if lru is not None else LRU(self.Q)
+        self.qp = qp if qp is not None else np.zeros(self.Q, dtype=np.uint8)
+        self._book = DcpHead.__new__(DcpHead)    # reuse the bookkeeping half
+        self._book.L, self._book.lru, self._book.qp = self.L, self.lru, self.qp
+        self._ws, self._ws_key = None, None
+
+    def _cfg(self, B):
+        return HeadCfg(B, self.D, self.Qs, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
+                       int(self.precise), 0, self.slot_lo, 0)
+
+    def partial(self, p_all, g_all, probe_label, gallery_label, transactional):
+        B = int(p_all.shape[0])
+        tab, plan, undo = self._book.assign(probe_label, gallery_label, transactional)
+        dev = p_all.device
+        tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
+        cfg = self._cfg(B)
+        if self._ws_key != B:
+            fn = self.L.vlsfr_head_workspace_bytes
+            fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.POINTER(HeadCfg)]
+            self._ws = torch.empty(fn(ctypes.byref(cfg)), dtype=torch.uint8, device=dev)
+            self._ws_key = B
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        st = dict(M=f32(B, 2), L=f32(B, 2), zt=f32(B, 2), O=f32(B, 2, self.D), T=f32(B, 2, self.D),
+                  cand_val=f32(B, 2, 10), cand_col=torch.empty(B, 2, 10, dtype=torch.int32, device=dev))
+        pd, gd = p_all.detach().float().contiguous(), g_all.detach().float().contiguous()
+        base, n = tab_d.data_ptr(), B
+        at = lambda k: ctypes.c_void_p(base + 4 * k * n)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        fn = self.L.vlsfr_head_shard_partial
+        fn.restype = ctypes.c_int
+        _lib.check(fn(ctypes.byref(cfg), P(pd), P(gd), P(self.queue), at(0), at(1), at(4), at(7),
+                      ctypes.c_int32(plan.n_special), ctypes.c_int32(plan.n_pos), P(st["M"]), P(st["L"]), P(st["zt"]),
+                      P(st["O"]), P(st["T"]), P(st["cand_val"]), P(st["cand_col"]), P(self._ws),
+                      ctypes.c_size_t(self._ws.numel()), _stream_ptr()), "vlsfr_head_shard_partial")
+        if transactional:
+            self._book.undo(plan, undo)
+        st.update(tab_d=tab_d, plan=plan, cfg=cfg, pd=pd, gd=gd, transactional=transactional,
+                  label=torch.from_numpy(tab[:n].copy()).to(dev))
+        return st
+
+    def combine(self, st, comm):
+        """comm: all_reduce_max(t), all_reduce_sum(t), all_gather(t) -> [world, ...] (in place / returned)."""
+        B, k = st["M"].shape[0], self.hard_neg
+        plan = st["plan"]
+        n_out = B - plan.n_pos
+        M = comm.all_reduce_max(st["M"].clone())
+        w = torch.exp2(st["M"] - M)                                        # [B, 2] rescale to the global maximum
+        w = torch.where(st["M"] <= -1e29, torch.zeros_like(w), w)
+        sel_loss = torch.zeros(B, 2, device=M.device)
+        if n_out > 0:                                                        # hard negatives: global top-k of the candidates
+            cv = comm.all_gather(st["cand_val"])                             # [W, B, 2, 10]
+            cc = comm.all_gather(st["cand_col"])
+            cv = cv.permute(1, 2, 0, 3).reshape(B, 2, -1)
+            cc = cc.permute(1, 2, 0, 3).reshape(B, 2, -1)
+            top, idx = torch.topk(cv, k, dim=2)
+            col = torch.gather(cc, 2, idx)
+            ok = (top > -1e29) & (col >= 0) & (top >= 0)                     # clip(min=0): negatives contribute nothing
+            inv = 1.0 / (n_out * k)
+            sel_w = torch.where(ok, torch.full_like(top, inv), torch.zeros_like(top))
+            is_out = (st["label"] < 0).view(B, 1, 1)
+            sel_w = sel_w * is_out
+            sel_loss = (torch.clamp(top, min=0) * (top > -1e29) * is_out).sum(2) * inv
+            fn = self.L.vlsfr_head_outlier_accum
+            fn.restype = ctypes.c_int
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            base, n = st["tab_d"].data_ptr(), B
+            at = lambda j: ctypes.c_void_p(base + 4 * j * n)
+            col_c, w_c = col.contiguous().int(), sel_w.contiguous().float()
+            _lib.check(fn(ctypes.byref(st["cfg"]), P(st["gd"]), P(self.queue), at(1), at(4), at(7),
+                          ctypes.c_int32(plan.n_special), P(col_c), P(w_c), ctypes.c_int32(k), P(st["T"]),
+                          _stream_ptr()), "vlsfr_head_outlier_accum")
+            st["_keep"] = (col_c, w_c)
+        packed = torch.cat([st["O"] * w.unsqueeze(2), st["T"], (st["L"] * w).unsqueeze(2), st["zt"].unsqueeze(2)], dim=2)
+        packed = comm.all_reduce_sum(packed.contiguous())
+        st.update(Mg=M, packed=packed, sel_loss=sel_loss)
+        return st
+
+    def finish(self, st):
+        """Loss (identical on every rank) and dL/dp for all rows of the batch."""
+        D, plan = self.D, st["plan"]
+        O, T = st["packed"][:, :, :D], st["packed"][:, :, D:2 * D]
+        Lg, zt = st["packed"][:, :, 2 * D], st["packed"][:, :, 2 * D + 1]
+        pos = (st["label"] >= 0).view(-1, 1)
+        inv_pos = 1.0 / max(plan.n_pos, 1)
+        safe_L = torch.where(pos, Lg, torch.ones_like(Lg))
+        row_loss = torch.where(pos, (0.6931471805599453 * (st["Mg"] + torch.log2(safe_L)) - zt) * inv_pos, st["sel_loss"])
+        dP = torch.where(pos.unsqueeze(2), self.scale * inv_pos * O / safe_L.unsqueeze(2) + T, T).sum(1)
+        if not st["transactional"]:
+            sc = self.L.vlsfr_pool_scatter
+            sc.restype = ctypes.c_int
+            base, n = st["tab_d"].data_ptr(), int(st["M"].shape[0])
+            at = lambda j: ctypes.c_void_p(base + 4 * j * n)
+            _lib.check(sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Qs), ctypes.c_int32(D),
+                          ctypes.c_void_p(st["gd"].data_ptr()), at(10), at(11), ctypes.c_int32(n),
+                          ctypes.c_int32(self.slot_lo), _stream_ptr()), "vlsfr_pool_scatter")
+        self._keep = st
+        return row_loss.sum(), dP

@@ -91,10 +91,12 @@ def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_
             if lr_policy == 'ReduceLROnPlateau':
                 lr_scheduler.step(loss_val)
             start = time.time()
+            # the sharded pool is gathered by every rank (a collective), rank 0 writes the file
+            pool = step_model.gather_pool() if hasattr(step_model, 'gather_pool') else ffc_net.queue
             if conf.saved_dir and (world == 1 or torch.distributed.get_rank() == 0):
                 os.makedirs(conf.saved_dir, exist_ok=True)
                 torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict(),
-                            'fc': ffc_net.queue.cpu(), 'qp': ffc_net.queue_position_dict.to_dict()},
+                            'fc': pool.cpu(), 'qp': ffc_net.queue_position_dict.to_dict()},
                            os.path.join(conf.saved_dir, '%d.pt' % (real_iter // conf.print_freq)))
     return real_iter, loss
 
@@ -115,8 +117,9 @@ def train(conf, log=print):
     optim, lr_scheduler = get_optim_scheduler([p for p in ffc_net.parameters() if p.requires_grad], optim_config)
     step_model = ffc_net
     if world > 1:
-        from .parallel import DataParallelFFC
-        step_model = DataParallelFFC(ffc_net, dist)
+        from .parallel import DataParallelFFC, ShardedFFC
+        sharded = conf.queue_size % world == 0 and conf.loss_type != "SV"
+        step_model = ShardedFFC(ffc_net, dist) if sharded else DataParallelFFC(ffc_net, dist)
     rank = dist.get_rank() if dist else 0
     real_iter, loss = 0, None
     for epoch in range(optim_config['epochs']):                                    # main.py:134-140

@@ -7,11 +7,14 @@ The reference has no distributed code; the semantics defined here
   * backbones: data parallel — every rank runs its own B rows; parameter gradients are summed
     with one all-reduce over a flat gradient buffer (the loss normalisers are already global, so the
     sum is the reference gradient);
-  * Dynamic Class Pool (round 1): replicated — the gallery embeddings g and both label vectors are
-    all-gathered (g over RCCL, the labels over a gloo side group so no device sync is needed), every
-    rank replays the identical LRU bookkeeping and pool writes, and sweeps the pool for its own B
-    probe rows.  No softmax collective is needed in this form; identity-sharding of the pool with a
-    softmax all-reduce is the next step.
+  * Dynamic Class Pool, two forms:
+      - `ShardedFFC` (default for N > 1): the pool is split by slot range over the ranks
+        (queue[2, Q/W, D] per GPU).  p, g are all-gathered over RCCL, the labels over a gloo side group
+        (no device sync); every rank replays the identical LRU bookkeeping, sweeps ITS slots for ALL
+        rows, and the softmax state is combined with all-reduce(max) + all-reduce(sum) of
+        (O, T, L, zt) (head.ShardedDcpHead) — three small collectives per pass.
+      - `DataParallelFFC`: replicated pool, every rank sweeps the whole pool for its own rows; no
+        softmax collective (kept for SV and as the A/B baseline).
 """
 import numpy as np
 import torch
@@ -89,3 +92,76 @@ class DataParallelFFC(object):
         t = loss.detach().clone()
         self.dist.all_reduce(t)
         return t
+
+
+class _DistComm(object):
+    """The three collectives of head.ShardedDcpHead over torch.distributed (RCCL; gloo rehearsal via host)."""
+
+    def __init__(self, dist, rccl):
+        self.dist, self.rccl, self.world = dist, rccl, dist.get_world_size()
+
+    def _reduce(self, t, op):
+        if self.rccl:
+            self.dist.all_reduce(t, op=op)
+            return t
+        c = t.cpu()
+        self.dist.all_reduce(c, op=op)
+        return c.to(t.device)
+
+    def all_reduce_max(self, t):
+        return self._reduce(t, self.dist.ReduceOp.MAX)
+
+    def all_reduce_sum(self, t):
+        return self._reduce(t, self.dist.ReduceOp.SUM)
+
+    def all_gather(self, t):
+        t = t.contiguous()
+        if self.rccl:
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            self.dist.all_gather_into_tensor(out, t)
+            return out
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+        self.dist.all_gather(parts, t.cpu())
+        return torch.stack(parts).to(t.device)
+
+
+class ShardedFFC(DataParallelFFC):
+    """Identity-sharded pool: after construction `model.queue` holds only this rank's slots
+    [rank * Q / W, (rank + 1) * Q / W) (use `gather_pool()` for a checkpoint)."""
+
+    def __init__(self, model, dist):
+        super(ShardedFFC, self).__init__(model, dist)
+        from .head import ShardedDcpHead
+        Q = model.queue_size
+        if Q % self.world:
+            raise ValueError("queue_size must be divisible by the number of ranks for the sharded pool")
+        Qs = Q // self.world
+        shard = model.queue[:, self.rank * Qs:(self.rank + 1) * Qs].contiguous()
+        state = model._state()
+        model.queue = shard                      # releases the full replica
+        model._head = None
+        self.head = ShardedDcpHead(shard, self.rank, self.world, Q, model.scale, model.margin, model.loss_type,
+                                   precise=model.precise_head, lru=state.lru, qp=state.qp)
+        self.comm = _DistComm(dist, self.rccl)
+
+    def gather_pool(self):
+        return self.comm.all_gather(self.head.queue).permute(1, 0, 2, 3).reshape(2, -1, self.head.D)
+
+    def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
+        from .head import _HeadFn
+        m = self.m
+        p = m.probe_net(p_data)
+        with torch.no_grad():
+            if transactional:
+                m._momentum_update_gallery()
+            g = m.gallery_net(g_data)
+            g_all = self._gather_rows(g)
+            p_all = self._gather_rows(p.detach())
+        pl = self._gather_labels(probe_label)
+        gl = self._gather_labels(gallery_label)
+        st = self.head.partial(p_all, g_all, pl, gl, transactional)
+        st = self.head.combine(st, self.comm)
+        loss, dP = self.head.finish(st)
+        B = p.shape[0]
+        # every rank holds the same global loss; its autograd edge carries this rank's rows of dL/dp
+        return _HeadFn.apply(p, loss.reshape(()), dP[self.rank * B:(self.rank + 1) * B].contiguous())
