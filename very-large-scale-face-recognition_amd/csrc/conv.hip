@@ -305,7 +305,10 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
 
 template <int BM, int BN, int BK, int NST>
 __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
-  constexpr int MT = BM / 32, NT = BN / 32;
+  // wave grid: 2 x 2 waves for the square tile; 1 x 4 for the 64-channel tile (64 x 256), so that every
+  // wave keeps a 64 x 64 sub-tile (MT = NT = 4) and the same MFMA : fragment-read ratio
+  constexpr int WM = BM >= 128 ? 2 : 1, WN = 4 / WM;
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
   constexpr int RSB = BK * 2;           // LDS row bytes
   constexpr int CPR = BK / 8;           // 16-byte chunks per row
   constexpr int RPI = 1024 / RSB;       // rows covered by one 1-KiB LDS-DMA wave-instruction
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, h = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int P = a.Nimg * a.Ho * a.Wo;
   const int K = a.R * a.S * a.C;
   const int m0 = blockIdx.y * BM;
@@ -448,8 +451,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) {
       const uint32_t rd = sbase + (uint32_t)(r16 * RSB + (((kk * 4 + h) ^ swz<BK>(r16)) << 4));
-      lds_read_frags<16 * RSB, 0>(fa[kk], rd + (uint32_t)(wm * (BM / 2) * RSB), std::make_integer_sequence<int, MT>{});
-      lds_read_frags<16 * RSB, BM * RSB>(fb[kk], rd + (uint32_t)(wn * (BN / 2) * RSB),
+      lds_read_frags<16 * RSB, 0>(fa[kk], rd + (uint32_t)(wm * (BM / WM) * RSB), std::make_integer_sequence<int, MT>{});
+      lds_read_frags<16 * RSB, BM * RSB>(fb[kk], rd + (uint32_t)(wn * (BN / WN) * RSB),
                                          std::make_integer_sequence<int, NT>{});
     }
 #pragma unroll
@@ -474,11 +477,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
     for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int p = p0 + wn * (BN / 2) + j * 16 + r16;
+    const int p = p0 + wn * (BN / WN) + j * 16 + r16;
     if (p >= P) continue;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h;
+      const int m = m0 + wm * (BM / WM) + i * 16 + 4 * h;
       if (m >= a.Mrows) continue;
       if (a.out_f32) {
         float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
           s += __shfl_xor(s, o, 64);
           q += __shfl_xor(q, o, 64);
         }
-        const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h + e;
+        const int m = m0 + wm * (BM / WM) + i * 16 + 4 * h + e;
         if (r16 == 0 && m < a.Mrows) {
           atomicAdd(dst + m, s);
           atomicAdd(dst + a.Mrows + m, q);
@@ -726,6 +729,11 @@ void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "bn_block_kb")) {
+    extern int g_bn_block_bytes;
+    g_bn_block_bytes = value > 0 ? value * 1024 : 65536;
     return VLSFR_OK;
   }
   return fail(VLSFR_EINVAL, "vlsfr_set_option: unknown option");

@@ -188,35 +188,46 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
   if (m.active) {
-    for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
-      bf8 xv, rs;
-      xv.raw = *(const uint4*)(a.x + r * C + m.col * 8);
-      if (a.residual) rs.raw = *(const uint4*)(a.residual + r * C + m.col * 8);
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float z = xv.get(j) * sc[j] + sf[j];
-        if (a.slope) z = z > 0.f ? z : z * sl[j];
-        if (a.residual) z += rs.get(j);
-        o[j] = z;
+    // two independent rows per iteration: both rows' loads are issued before either is consumed
+    for (int64_t r = r0 + m.rl; r < r1; r += 2 * m.rpb) {
+      const int64_t rr[2] = {r, r + m.rpb};
+      const bool ok1 = rr[1] < r1;
+      bf8 xv[2], rs[2];
+      xv[0].raw = *(const uint4*)(a.x + rr[0] * C + m.col * 8);
+      if (ok1) xv[1].raw = *(const uint4*)(a.x + rr[1] * C + m.col * 8);
+      if (a.residual) {
+        rs[0].raw = *(const uint4*)(a.residual + rr[0] * C + m.col * 8);
+        if (ok1) rs[1].raw = *(const uint4*)(a.residual + rr[1] * C + m.col * 8);
       }
-      const uint4 packed = pack8(o);
-      if (!a.out_nchw) {
-        *(uint4*)(a.y + r * C + m.col * 8) = packed;
-      } else {
-        const int64_t n = r / a.HW;
-        const int hw = (int)(r - n * a.HW);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a.y[(n * C + m.col * 8 + j) * a.HW + hw] = f2bf(o[j]);
-      }
-      if (a.out_sums) {
-        bf8 yv;
-        yv.raw = packed;   // statistics of what the next layer will actually read
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !ok1) break;
+        float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float f = yv.get(j);
-          v[0][j] += f;
-          v[1][j] += f * f;
+          float z = xv[u].get(j) * sc[j] + sf[j];
+          if (a.slope) z = z > 0.f ? z : z * sl[j];
+          if (a.residual) z += rs[u].get(j);
+          o[j] = z;
+        }
+        const uint4 packed = pack8(o);
+        if (!a.out_nchw) {
+          *(uint4*)(a.y + rr[u] * C + m.col * 8) = packed;
+        } else {
+          const int64_t n = rr[u] / a.HW;
+          const int hw = (int)(rr[u] - n * a.HW);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) a.y[(n * C + m.col * 8 + j) * a.HW + hw] = f2bf(o[j]);
+        }
+        if (a.out_sums) {
+          bf8 yv;
+          yv.raw = packed;   // statistics of what the next layer will actually read
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float f = yv.get(j);
+            v[0][j] += f;
+            v[1][j] += f * f;
+          }
         }
       }
     }
@@ -258,13 +269,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   extern __shared__ float sh[];
   const int C = a.C;
   const RowMap m = row_map(C);
-  float v[3][8], mu[8], is[8], g[8], b[8], sl[8];
+  float v[3][8], xs[8], xo[8], g[8], b[8], sl[8];   // xhat = x * xs + xo
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
     v[0][j] = v[1][j] = v[2][j] = 0.f;
-    mu[j] = a.mean[c];
-    is[j] = a.invstd[c];
+    xs[j] = a.invstd[c];
+    xo[j] = -a.mean[c] * a.invstd[c];
     g[j] = a.gamma ? a.gamma[c] : 1.f;
     b[j] = a.beta ? a.beta[c] : 0.f;
     sl[j] = a.slope ? a.slope[c] : 1.f;
@@ -272,24 +283,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
   if (m.active) {
-    for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
-      bf8 xv, dv;
-      xv.raw = *(const uint4*)(a.x + r * C + m.col * 8);
-      if (!a.dy_nchw) dv.raw = *(const uint4*)(a.dy + r * C + m.col * 8);
+    for (int64_t r = r0 + m.rl; r < r1; r += 2 * m.rpb) {
+      const int64_t rr[2] = {r, r + m.rpb};
+      const bool ok1 = rr[1] < r1;
+      bf8 xv[2], dv[2];
+      xv[0].raw = *(const uint4*)(a.x + rr[0] * C + m.col * 8);
+      if (ok1) xv[1].raw = *(const uint4*)(a.x + rr[1] * C + m.col * 8);
+      if (!a.dy_nchw) {
+        dv[0].raw = *(const uint4*)(a.dy + rr[0] * C + m.col * 8);
+        if (ok1) dv[1].raw = *(const uint4*)(a.dy + rr[1] * C + m.col * 8);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xhat = (xv.get(j) - mu[j]) * is[j];
-        const float dyv = a.dy_nchw ? load_dy_nchw(a, r, m.col * 8 + j) : dv.get(j);
-        float dz = dyv;
-        if (a.slope) {
-          const float z = xhat * g[j] + b[j];
-          if (z <= 0.f) {
-            v[2][j] += dyv * z;
-            dz = dyv * sl[j];
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !ok1) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xhat = xv[u].get(j) * xs[j] + xo[j];
+          const float dyv = a.dy_nchw ? load_dy_nchw(a, rr[u], m.col * 8 + j) : dv[u].get(j);
+          float dz = dyv;
+          if (a.slope) {
+            const float z = xhat * g[j] + b[j];
+            if (z <= 0.f) {
+              v[2][j] += dyv * z;
+              dz = dyv * sl[j];
+            }
           }
+          v[0][j] += dz;
+          v[1][j] += dz * xhat;
         }
-        v[0][j] += dz;
-        v[1][j] += dz * xhat;
       }
     }
   }
@@ -322,40 +343,53 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   __syncthreads();
   const RowMap m = row_map(C);
   if (!m.active) return;
-  float k0[8], k1[8], k2[8], mu[8], is[8], g[8], b[8], sl[8];
+  float k0[8], k1[8], k2[8], xs[8], xo[8], g[8], b[8], sl[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
     k0[j] = sh[c];
     k1[j] = sh[C + c];
     k2[j] = sh[2 * C + c];
-    mu[j] = a.mean[c];
-    is[j] = a.invstd[c];
+    xs[j] = a.invstd[c];
+    xo[j] = -a.mean[c] * a.invstd[c];
     g[j] = a.gamma ? a.gamma[c] : 1.f;
     b[j] = a.beta ? a.beta[c] : 0.f;
     sl[j] = a.slope ? a.slope[c] : 1.f;
   }
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
-  for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
-    bf8 xv, dv, av;
-    xv.raw = *(const uint4*)(a.x + r * C + m.col * 8);
-    if (!a.dy_nchw) dv.raw = *(const uint4*)(a.dy + r * C + m.col * 8);
-    if (a.dx_add) av.raw = *(const uint4*)(a.dx_add + r * C + m.col * 8);
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xhat = (xv.get(j) - mu[j]) * is[j];
-      float dz = a.dy_nchw ? load_dy_nchw(a, r, m.col * 8 + j) : dv.get(j);
-      if (a.slope) {
-        const float z = xhat * g[j] + b[j];
-        if (z <= 0.f) dz *= sl[j];
-      }
-      float d = k0[j] * (dz - k1[j] - xhat * k2[j]);
-      if (a.dx_add) d += av.get(j);
-      o[j] = d;
+  for (int64_t r = r0 + m.rl; r < r1; r += 2 * m.rpb) {
+    const int64_t rr[2] = {r, r + m.rpb};
+    const bool ok1 = rr[1] < r1;
+    bf8 xv[2], dv[2], av[2];
+    xv[0].raw = *(const uint4*)(a.x + rr[0] * C + m.col * 8);
+    if (ok1) xv[1].raw = *(const uint4*)(a.x + rr[1] * C + m.col * 8);
+    if (!a.dy_nchw) {
+      dv[0].raw = *(const uint4*)(a.dy + rr[0] * C + m.col * 8);
+      if (ok1) dv[1].raw = *(const uint4*)(a.dy + rr[1] * C + m.col * 8);
     }
-    *(uint4*)(a.dx + r * C + m.col * 8) = pack8(o);
+    if (a.dx_add) {
+      av[0].raw = *(const uint4*)(a.dx_add + rr[0] * C + m.col * 8);
+      if (ok1) av[1].raw = *(const uint4*)(a.dx_add + rr[1] * C + m.col * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !ok1) break;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xhat = xv[u].get(j) * xs[j] + xo[j];
+        float dz = a.dy_nchw ? load_dy_nchw(a, rr[u], m.col * 8 + j) : dv[u].get(j);
+        if (a.slope) {
+          const float z = xhat * g[j] + b[j];
+          if (z <= 0.f) dz *= sl[j];
+        }
+        float d = k0[j] * (dz - k1[j] - xhat * k2[j]);
+        if (a.dx_add) d += av[u].get(j);
+        o[j] = d;
+      }
+      *(uint4*)(a.dx + rr[u] * C + m.col * 8) = pack8(o);
+    }
   }
 }
 
@@ -561,11 +595,13 @@ inline int blocks_for(int64_t work_items, int per_block = 256, int cap = 2048) {
 
 extern "C" {
 
+int g_bn_block_bytes = 65536;   // bytes of x per block (vlsfr_set_option("bn_block_kb", v))
+
 static int bn_geom(int64_t M, int C, int* RB, int* nblk) {
   const int cg = C / 8;
   const int rpb = 256 / cg;
   if (rpb < 1) return -1;
-  int rb = 32768 / (C * 2);
+  int rb = g_bn_block_bytes / (C * 2);
   if (rb < rpb) rb = rpb;
   rb = (rb / rpb) * rpb;
   *RB = rb;
