@@ -9,40 +9,32 @@ from torch import nn
 from .. import _lib
 from ._native import NativeBackbone
 
-MobileFaceNet_BottleNeck_Setting = [
-    # t, c , n ,s
-    [2, 64, 5, 2],
-    [4, 128, 1, 2],
-    [2, 128, 6, 1],
-    [4, 128, 1, 2],
-    [2, 128, 2, 1],
-]
+# (expansion t, output channels c, repeats n, stride of the first repeat s) — mobilefacenet_def.py:18-25
+BOTTLENECKS = ((2, 64, 5, 2), (4, 128, 1, 2), (2, 128, 6, 1), (4, 128, 1, 2), (2, 128, 2, 1))
+MobileFaceNet_BottleNeck_Setting = [list(r) for r in BOTTLENECKS]
 
 
-class BottleNeck(nn.Module):
-    def __init__(self, inp, oup, stride, expansion):
-        super(BottleNeck, self).__init__()
-        self.connect = stride == 1 and inp == oup
-        self.conv = nn.Sequential(
-            nn.Conv2d(inp, inp * expansion, 1, 1, 0, bias=False),
-            nn.BatchNorm2d(inp * expansion),
-            nn.PReLU(inp * expansion),
-            nn.Conv2d(inp * expansion, inp * expansion, 3, stride, 1, groups=inp * expansion, bias=False),
-            nn.BatchNorm2d(inp * expansion),
-            nn.PReLU(inp * expansion),
-            nn.Conv2d(inp * expansion, oup, 1, 1, 0, bias=False),
-            nn.BatchNorm2d(oup),
-        )
+def _unit(cin, cout, k, stride, pad, depthwise=False, act=True):
+    """Parameter container with the reference ConvBlock's attribute names: conv, bn[, prelu]."""
+    m = nn.Module()
+    m.add_module("conv", nn.Conv2d(cin, cout, k, stride, pad, groups=cin if depthwise else 1, bias=False))
+    m.add_module("bn", nn.BatchNorm2d(cout))
+    if act:
+        m.add_module("prelu", nn.PReLU(cout))
+    return m
 
 
-class ConvBlock(nn.Module):
-    def __init__(self, inp, oup, k, s, p, dw=False, linear=False):
-        super(ConvBlock, self).__init__()
-        self.linear = linear
-        self.conv = nn.Conv2d(inp, oup, k, s, p, groups=inp if dw else 1, bias=False)
-        self.bn = nn.BatchNorm2d(oup)
-        if not linear:
-            self.prelu = nn.PReLU(oup)
+def _bottleneck(cin, cout, stride, t):
+    """Parameter container with the reference BottleNeck's layout: `.conv` = Sequential of
+    pointwise / BN / PReLU / depthwise / BN / PReLU / pointwise / BN (indices 0..7)."""
+    mid = cin * t
+    seq = [nn.Conv2d(cin, mid, 1, bias=False), nn.BatchNorm2d(mid), nn.PReLU(mid),
+           nn.Conv2d(mid, mid, 3, stride, 1, groups=mid, bias=False), nn.BatchNorm2d(mid), nn.PReLU(mid),
+           nn.Conv2d(mid, cout, 1, bias=False), nn.BatchNorm2d(cout)]
+    m = nn.Module()
+    m.add_module("conv", nn.Sequential(*seq))
+    m.connect = stride == 1 and cin == cout
+    return m
 
 
 class MobileFaceNet(NativeBackbone):
@@ -53,18 +45,18 @@ class MobileFaceNet(NativeBackbone):
         if [list(r) for r in bottleneck_setting] != MobileFaceNet_BottleNeck_Setting:
             raise _lib.VlsfrError("MobileFaceNet: only the reference bottleneck table is covered by the native executor")
         self.feat_dim, self.image_size, self.fp16 = int(feat_dim), 112, fp16
-        self.conv1 = ConvBlock(3, 64, 3, 2, 1)
-        self.dw_conv1 = ConvBlock(64, 64, 3, 1, 1, dw=True)
-        self.cur_channel = 64
-        layers = []
-        for t, c, n, s in bottleneck_setting:
+        self.conv1 = _unit(3, 64, 3, 2, 1)
+        self.dw_conv1 = _unit(64, 64, 3, 1, 1, depthwise=True)
+        width, blocks = 64, []
+        for t, c, n, s in BOTTLENECKS:
             for i in range(n):
-                layers.append(BottleNeck(self.cur_channel, c, s if i == 0 else 1, t))
-                self.cur_channel = c
-        self.blocks = nn.Sequential(*layers)
-        self.conv2 = ConvBlock(128, 512, 1, 1, 0)
-        self.linear7 = ConvBlock(512, 512, 7, 1, 0, dw=True, linear=True)
-        self.linear1 = ConvBlock(512, feat_dim, 1, 1, 0, linear=True)
+                blocks.append(_bottleneck(width, c, s if i == 0 else 1, t))
+                width = c
+        self.cur_channel = width
+        self.blocks = nn.Sequential(*blocks)
+        self.conv2 = _unit(128, 512, 1, 1, 0)
+        self.linear7 = _unit(512, 512, 7, 1, 0, depthwise=True, act=False)
+        self.linear1 = _unit(512, feat_dim, 1, 1, 0, act=False)
         # the stem weight is read as [64][3][3][3] = channels_last memory; 1x1 and depthwise weights are
         # the same bytes in either format
         self.conv1.conv.weight.data = self.conv1.conv.weight.data.contiguous(memory_format=__import__("torch").channels_last)

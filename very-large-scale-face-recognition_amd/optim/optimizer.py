@@ -1,8 +1,13 @@
-"""Optimizer + LR schedule factory with the reference's contract (optim/optimizer.py:6-45,142-168):
-``get_optim_scheduler(parameters, config) -> (optimizer, scheduler)``; schedulers expose
-``update(cur_epoch, cur_iter)``, ``get_lr()``, ``state_dict()`` / ``load_state_dict()``.
-The SGD branch returns the fused gfx950 step (optim/fused.py) behind the torch Optimizer interface;
-the schedules are host arithmetic."""
+"""Optimizer + learning-rate schedule factory honouring the reference's contract
+(optim/optimizer.py:6-45 scheduler interface, :142-168 factory):
+
+    optimizer, scheduler = get_optim_scheduler(parameters, config_dict)
+    scheduler.update(cur_epoch: int | None, cur_iter: float | None)      # main.py:39-40,138-139
+    scheduler.get_lr() -> list;  scheduler.state_dict() / load_state_dict()
+
+The SGD branch returns the fused gfx950 step (optim/fused.py) behind the torch Optimizer interface.
+The four warm-up schedules are one class parameterised by a decay rule (host arithmetic only).
+"""
 import math
 from bisect import bisect_right
 
@@ -12,48 +17,48 @@ from torch.optim import Optimizer
 from .fused import FusedSGD
 
 
-class WarmupSchedule(object):
-    """Base of the four schedules: linear warm-up over `warmup_epochs`, then `_after(base_lr, e)`
-    with e = epochs since warm-up (reference _LRScheduler, optim/optimizer.py:6-45)."""
+def _rule_multistep(s, base, e):          # optim/optimizer.py:68-89
+    lr = base
+    for g in s.gammas[:bisect_right(s.milestones, e)]:
+        lr *= g
+    return lr
 
-    def __init__(self, optimizer, warmup_epochs, epochs):
+
+def _rule_cosine(s, base, e):             # optim/optimizer.py:47-66 (the stray print at :64 is not reproduced)
+    return s.eta_min + (base - s.eta_min) * (1 + math.cos(math.pi * e / s.T_max)) / 2
+
+
+def _rule_exponential(s, base, e):        # optim/optimizer.py:91-107
+    return base * (s.gamma ** e)
+
+
+def _rule_linear(s, base, e):             # optim/optimizer.py:109-128
+    return base * (1 - (s.max_LR - s.min_LR) * e / s.max_epochs / s.max_LR)
+
+
+_RULES = dict(multistep=_rule_multistep, cos=_rule_cosine, exponential=_rule_exponential, linear=_rule_linear)
+
+
+class WarmupSchedule(object):
+    """lr(epoch, iter) = base * (epoch + iter) / warmup while epoch < warmup, then rule(base, epoch - warmup)."""
+
+    def __init__(self, optimizer, kind, warmup_epochs, epochs, **hyper):
         if not isinstance(optimizer, Optimizer):
             raise TypeError('{:} is not an Optimizer'.format(type(optimizer).__name__))
         self.optimizer = optimizer
-        for group in optimizer.param_groups:
-            group.setdefault('initial_lr', group['lr'])
-        self.base_lrs = [group['initial_lr'] for group in optimizer.param_groups]
-        self.max_epochs = epochs
-        self.warmup_epochs = warmup_epochs
-        self.current_epoch = 0
-        self.current_iter = 0
-
-    def state_dict(self):
-        return {k: v for k, v in self.__dict__.items() if k != 'optimizer'}
-
-    def load_state_dict(self, state_dict):
-        self.__dict__.update(state_dict)
-
-    def _after(self, base_lr, e):
-        raise NotImplementedError
+        self.kind = kind
+        self.base_lrs = [g.setdefault('initial_lr', g['lr']) for g in optimizer.param_groups]
+        self.max_epochs, self.warmup_epochs = epochs, warmup_epochs
+        self.current_epoch, self.current_iter = 0, 0
+        self.__dict__.update(hyper)
 
     def get_lr(self):
-        if self.current_epoch >= self.warmup_epochs:
-            return [self._after(b, self.current_epoch - self.warmup_epochs) for b in self.base_lrs]
-        frac = self.current_epoch / self.warmup_epochs + self.current_iter / self.warmup_epochs
-        return [frac * b for b in self.base_lrs]
-
-    def get_min_lr(self):
-        return min(self.get_lr())
-
-    def get_min_info(self):
-        lrs = self.get_lr()
-        return '#LR=[{:.6f}~{:.6f}] epoch={:03d}, iter={:4.2f}#'.format(min(lrs), max(lrs), self.current_epoch,
-                                                                        self.current_iter)
-
-    def __repr__(self):
-        return '{:}(warmup={:}, max-epoch={:}, current::epoch={:}, iter={:.2f})'.format(
-            self.__class__.__name__, self.warmup_epochs, self.max_epochs, self.current_epoch, self.current_iter)
+        e, w = self.current_epoch, self.warmup_epochs
+        if e < w:
+            return [(e / w + self.current_iter / w) * b for b in self.base_lrs]
+        if self.kind == 'cos' and e >= self.max_epochs:
+            return [self.eta_min for _ in self.base_lrs]
+        return [_RULES[self.kind](self, b, e - w) for b in self.base_lrs]
 
     def update(self, cur_epoch, cur_iter):
         if cur_epoch is not None:
@@ -65,76 +70,51 @@ class WarmupSchedule(object):
         for group, lr in zip(self.optimizer.param_groups, self.get_lr()):
             group['lr'] = lr
 
+    def get_min_lr(self):
+        return min(self.get_lr())
 
-class CosineAnnealingLR(WarmupSchedule):       # optim/optimizer.py:47-66 (without the stray print at :64)
-    def __init__(self, optimizer, warmup_epochs, epochs, T_max, eta_min):
-        self.T_max, self.eta_min = T_max, eta_min
-        super(CosineAnnealingLR, self).__init__(optimizer, warmup_epochs, epochs)
+    def get_min_info(self):
+        lrs = self.get_lr()
+        return '#LR=[{:.6f}~{:.6f}] epoch={:03d}, iter={:4.2f}#'.format(min(lrs), max(lrs), self.current_epoch,
+                                                                        self.current_iter)
 
-    def get_lr(self):
-        if self.current_epoch >= self.max_epochs and self.current_epoch >= self.warmup_epochs:
-            return [self.eta_min for _ in self.base_lrs]
-        return super(CosineAnnealingLR, self).get_lr()
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != 'optimizer'}
 
-    def _after(self, base_lr, e):
-        return self.eta_min + (base_lr - self.eta_min) * (1 + math.cos(math.pi * e / self.T_max)) / 2
+    def load_state_dict(self, state):
+        self.__dict__.update(state)
 
-
-class MultiStepLR(WarmupSchedule):             # optim/optimizer.py:68-89
-    def __init__(self, optimizer, warmup_epochs, epochs, milestones, gammas):
-        assert len(milestones) == len(gammas), 'invalid {:} vs {:}'.format(len(milestones), len(gammas))
-        self.milestones, self.gammas = milestones, gammas
-        super(MultiStepLR, self).__init__(optimizer, warmup_epochs, epochs)
-
-    def _after(self, base_lr, e):
-        lr = base_lr
-        for g in self.gammas[:bisect_right(self.milestones, e)]:
-            lr *= g
-        return lr
+    def __repr__(self):
+        return 'WarmupSchedule({}, warmup={}, epochs={}, epoch={}, iter={:.2f})'.format(
+            self.kind, self.warmup_epochs, self.max_epochs, self.current_epoch, self.current_iter)
 
 
-class ExponentialLR(WarmupSchedule):           # optim/optimizer.py:91-107
-    def __init__(self, optimizer, warmup_epochs, epochs, gamma):
-        self.gamma = gamma
-        super(ExponentialLR, self).__init__(optimizer, warmup_epochs, epochs)
-
-    def _after(self, base_lr, e):
-        return base_lr * (self.gamma ** e)
-
-
-class LinearLR(WarmupSchedule):                # optim/optimizer.py:109-128
-    def __init__(self, optimizer, warmup_epochs, epochs, max_LR, min_LR):
-        self.max_LR, self.min_LR = max_LR, min_LR
-        super(LinearLR, self).__init__(optimizer, warmup_epochs, epochs)
-
-    def _after(self, base_lr, e):
-        return base_lr * (1 - (self.max_LR - self.min_LR) * e / self.max_epochs / self.max_LR)
-
-
-def get_optim_scheduler(parameters, config):   # optim/optimizer.py:142-168
+def get_optim_scheduler(parameters, config):
     assert 'optim' in config and 'scheduler' in config, \
         'config must have optim / scheduler / criterion keys instead of {:}'.format(config)
-    if config['optim'] == 'SGD':
+    name = config['optim']
+    if name == 'SGD':                       # optim/optimizer.py:148-150
         optim = FusedSGD(parameters, config['LR'], momentum=config['momentum'], weight_decay=config['decay'],
                          nesterov=config['nesterov'])
-    elif config['optim'] == 'RMSprop':
+    elif name == 'RMSprop':                 # :151-152 (not on the hot path: stock torch)
         optim = torch.optim.RMSprop(parameters, config['LR'], momentum=config['momentum'],
                                     weight_decay=config['decay'])
     else:
-        raise ValueError('invalid optim : {:}'.format(config['optim']))
-    sched = config['scheduler']
-    if sched == 'cos':
-        T_max = getattr(config, 'T_max', config['epochs'])   # a dict has no such attribute: always `epochs` (:156)
-        scheduler = CosineAnnealingLR(optim, config['warmup'], config['epochs'], T_max, config['eta_min'])
-    elif sched == 'multistep':
-        scheduler = MultiStepLR(optim, config['warmup'], config['epochs'], config['milestones'], config['gammas'])
-    elif sched == 'exponential':
-        scheduler = ExponentialLR(optim, config['warmup'], config['epochs'], config['gamma'])
-    elif sched == 'linear':
-        scheduler = LinearLR(optim, config['warmup'], config['epochs'], config['LR'], config['LR_min'])
-    elif sched == 'ReduceLROnPlateau':
-        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optim, patience=config['patience'],
-                                                               min_lr=config['LR_min'])
+        raise ValueError('invalid optim : {:}'.format(name))
+    kind, warm, epochs = config['scheduler'], config.get('warmup', 0), config.get('epochs', 1)
+    if kind == 'multistep':
+        assert len(config['milestones']) == len(config['gammas']), 'invalid {:} vs {:}'.format(
+            len(config['milestones']), len(config['gammas']))
+        sched = WarmupSchedule(optim, kind, warm, epochs, milestones=config['milestones'], gammas=config['gammas'])
+    elif kind == 'cos':
+        # the reference reads T_max with getattr() on a dict, which always yields `epochs` (:156)
+        sched = WarmupSchedule(optim, kind, warm, epochs, T_max=epochs, eta_min=config['eta_min'])
+    elif kind == 'exponential':
+        sched = WarmupSchedule(optim, kind, warm, epochs, gamma=config['gamma'])
+    elif kind == 'linear':
+        sched = WarmupSchedule(optim, kind, warm, epochs, max_LR=config['LR'], min_LR=config['LR_min'])
+    elif kind == 'ReduceLROnPlateau':
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(optim, patience=config['patience'], min_lr=config['LR_min'])
     else:
-        raise ValueError('invalid scheduler : {:}'.format(sched))
-    return optim, scheduler
+        raise ValueError('invalid scheduler : {:}'.format(kind))
+    return optim, sched
