@@ -37,7 +37,7 @@ IR_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["regstage", "glds64x4", "glds32x4", "glds64x2", "glds32x5"])
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["regstage", "glds64x4", "glds32x4", "glds64x2", "glds32x5", "glds8w"])
 def conv_variant(request):
     """Every implicit-GEMM kernel variant (register-staged, and the LDS-DMA rings) must agree."""
     import ctypes

@@ -303,17 +303,18 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
   ((f[I] = lds_read128_asm<BASE + I * STRIDE>(addr)), ...);
 }
 
-template <int BM, int BN, int BK, int NST>
-__global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
-  // wave grid: 2 x 2 waves for the square tile; 1 x 4 for the 64-channel tile (64 x 256), so that every
-  // wave keeps a 64 x 64 sub-tile (MT = NT = 4) and the same MFMA : fragment-read ratio
-  constexpr int WM = BM >= 128 ? 2 : 1, WN = 4 / WM;
+template <int BM, int BN, int BK, int NST, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a) {
+  // wave grid WM x WN (NW waves): each wave keeps (BM / WM) x (BN / WN) of the tile; the 8-wave
+  // 256 x 128 / 128 x 256 tiles raise the FLOPs per byte a CU has to pull from L2 by a third over
+  // the 4-wave 128 x 128 tile (the per-CU load path, not HBM, is what bounds this kernel)
+  constexpr int WM = (NW == 8) ? (BM / 64) : 2, WN = NW / WM;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
   constexpr int RSB = BK * 2;           // LDS row bytes
   constexpr int CPR = BK / 8;           // 16-byte chunks per row
   constexpr int RPI = 1024 / RSB;       // rows covered by one 1-KiB LDS-DMA wave-instruction
-  constexpr int AI = BM / (4 * RPI);    // LDS-DMA instructions per wave and stage, weight tile
-  constexpr int BI = BN / (4 * RPI);    // pixel tile
+  constexpr int AI = BM / (NW * RPI);   // LDS-DMA instructions per wave and stage, weight tile
+  constexpr int BI = BN / (NW * RPI);   // pixel tile
   constexpr int STAGE = (BM + BN) * RSB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -344,47 +345,65 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_glds_kernel(ConvArgs a) {
   }
   const u16* b_ptr[BI];
   uint32_t b_mask[BI];
+  {
+    // pixel coordinates: one division for the first row of this lane, the other rows (RPI pixels
+    // further each) by carry; tap validity as the outer product of 3 row bits and 3 column bits
+    int p = p0 + wave * BI * RPI + rsub;
+    const int HoWo = a.Ho * a.Wo;
+    const int pc = p < P ? p : (P > 0 ? P - 1 : 0);
+    int n = pc / HoWo;
+    int rem = pc - n * HoWo;
+    int ho = rem / a.Wo;
+    int wo = rem - ho * a.Wo;
 #pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int p = p0 + (wave * BI + i) * RPI + rsub;
-    const bool okp = p < P;
-    const int pp = okp ? p : 0;
-    const int n = pp / (a.Ho * a.Wo);
-    const int rem = pp - n * a.Ho * a.Wo;
-    const int ho = rem / a.Wo;
-    const int wo = rem - ho * a.Wo;
-    int bh, bw;
-    if (a.mode == 0) {
-      bh = ho * a.stride - a.pad;
-      bw = wo * a.stride - a.pad;
-    } else if (a.stride == 1) {
-      bh = ho + a.pad;
-      bw = wo + a.pad;
-    } else {
-      bh = (ho + a.pad) >> 1;
-      bw = (wo + a.pad) >> 1;
-    }
-    uint32_t mask = 0;
-    for (int r = 0; r < a.R; ++r)
-      for (int s = 0; s < a.S; ++s) {
+    for (int i = 0; i < BI; ++i) {
+      const bool okp = p < P;
+      int bh, bw;
+      if (a.mode == 0) {
+        bh = ho * a.stride - a.pad;
+        bw = wo * a.stride - a.pad;
+      } else if (a.stride == 1) {
+        bh = ho + a.pad;
+        bw = wo + a.pad;
+      } else {
+        bh = (ho + a.pad) >> 1;
+        bw = (wo + a.pad) >> 1;
+      }
+      uint32_t vh = 0, vw = 0;   // bit r / s set when tap row r / column s reads inside the gathered tensor
+      for (int r = 0; r < a.R; ++r) {
         int hi, wi;
-        bool ok = okp;
+        bool okh = true, okw = true;
         if (a.mode == 0) {
           hi = bh + r;
-          wi = bw + s;
+          wi = bw + r;
         } else if (a.stride == 1) {
           hi = bh - r;
-          wi = bw - s;
+          wi = bw - r;
         } else {
-          ok = ok && !(((ho + a.pad - r) | (wo + a.pad - s)) & 1);
+          okh = !((ho + a.pad - r) & 1);
+          okw = !((wo + a.pad - r) & 1);
           hi = bh - (r >> 1);
-          wi = bw - (s >> 1);
+          wi = bw - (r >> 1);
         }
-        ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        if (ok) mask |= 1u << (r * a.S + s);
+        if (okh && hi >= 0 && hi < a.H) vh |= 1u << r;
+        if (okw && wi >= 0 && wi < a.W) vw |= 1u << r;
       }
-    b_mask[i] = mask;
-    b_ptr[i] = a.x + (((int64_t)n * a.H + bh) * a.W + bw) * a.C + lchunk * 8;   // tap (0,0); only dereferenced when valid
+      uint32_t mask = 0;
+      for (int r = 0; r < a.R; ++r)
+        if (vh & (1u << r)) mask |= vw << (r * a.S);
+      b_mask[i] = okp ? mask : 0u;
+      b_ptr[i] = a.x + (((int64_t)n * a.H + bh) * a.W + bw) * a.C + lchunk * 8;   // tap (0,0); only dereferenced when valid
+      // advance RPI pixels
+      p += RPI;
+      wo += RPI;
+      while (wo >= a.Wo) {
+        wo -= a.Wo;
+        if (++ho >= a.Ho) {
+          ho = 0;
+          ++n;
+        }
+      }
+    }
   }
 
   // k-tile cursor of the NEXT tile to issue, advanced incrementally (no divisions in the loop)
@@ -677,18 +696,18 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
 
 inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-template <int BM, int BN, int BK, int NST>
+template <int BM, int BN, int BK, int NST, int NW = 4>
 int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr_set = false;
-  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST>;
+  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "conv_igemm_glds: hipFuncSetAttribute");
     attr_set = true;
   }
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, a);
   return VLSFR_OK;
 }
 
@@ -710,6 +729,12 @@ int run_igemm(ConvArgs a, hipStream_t st) {
     const bool big = a.Mrows >= 128;
     if (g_use_glds == 1) rc = big ? launch_igemm_glds<128, 128, 64, 4>(a, P, st) : launch_igemm_glds<64, 128, 64, 4>(a, P, st);
     else if (g_use_glds == 2) rc = big ? launch_igemm_glds<128, 128, 32, 4>(a, P, st) : launch_igemm_glds<64, 128, 32, 4>(a, P, st);
+    else if (g_use_glds == 5)   // 8-wave tiles, 3-stage ring, one workgroup per CU
+      rc = a.Mrows >= 256 ? launch_igemm_glds<256, 128, 64, 3, 8>(a, P, st)
+           : big          ? launch_igemm_glds<128, 256, 64, 3, 8>(a, P, st)
+                          : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
+    else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
     else rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     if (rc != VLSFR_OK) return rc;
