@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--feat", type=int, default=512)
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="name=value tuning switch (vlsfr_set_option), repeatable")
     ap.add_argument("--conv-glds", type=int, default=-1, help="A/B switch for the conv kernel variant (vlsfr_set_option)")
     ap.add_argument("--pool", default="sharded", choices=["sharded", "replicated"],
                     help="N > 1: identity-sharded pool (softmax all-reduce) or replicated pool")
@@ -171,6 +172,9 @@ def main():
     L = _lib.lib()
     if args.conv_glds >= 0:
         L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(args.conv_glds))
+    for kv in args.opt:
+        k, v = kv.split("=")
+        _lib.check(L.vlsfr_set_option(k.encode(), ctypes.c_int32(int(v))), "vlsfr_set_option")
     note("model on device, pool %d slots; warm-up" % Q)
     for i in range(args.warmup):
         one_step(i)
@@ -213,6 +217,17 @@ def main():
                     share_of_step=round(ms / (dt * 1e3), 3),
                     other={k: dict(total_ms=round(v[0], 2), tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                                    launches=int(v[2])) for k, v in fams.items() if k != dom})
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be collected from inside this
+    # process, so the figure measured by rocprofv3 --pmc on this same command (profiles/) is attached
+    # when the configuration matches
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt["config"] == {"net": args.net, "batch": B, "identities": args.identities}:
+            roofline["traffic"] = pt["kernels"][dom.replace("_kernel", "")]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+    except (OSError, KeyError, ValueError):
+        pass
     faces = world * 2 * B * args.steps
     out = {
         "metric": "faces/sec (whole node) at %s-identity FFC, %s" % (

@@ -36,7 +36,8 @@ struct ProfRec {
 };
 bool g_prof_on = false;
 #define VLSFR_DEFAULT_CONV_VARIANT 3
-int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
+int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;
+int g_wgrad_target = 1024;   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -584,6 +585,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   if (kt0 >= kt1) return;
 
   uint4 ra[ACH], rb[BCH];
+  // gathered-operand cursor per staged chunk: pixel coordinates of tile kt0, advanced by 32 pixels per
+  // k-tile with carries (no divisions in the loop)
+  int g_n[BCH], g_ho[BCH], g_wo[BCH];
+#pragma unroll
+  for (int u = 0; u < BCH; ++u) {
+    const int e = tid + 256 * u;
+    const int prow = e / (BN / 8);
+    const int64_t p = (int64_t)kt0 * 32 + prow;
+    const int64_t pc = p < P ? p : (P > 0 ? P - 1 : 0);
+    g_n[u] = (int)(pc / (a.Ho * a.Wo));
+    const int rem = (int)(pc - (int64_t)g_n[u] * a.Ho * a.Wo);
+    g_ho[u] = rem / a.Wo;
+    g_wo[u] = rem - g_ho[u] * a.Wo;
+  }
   auto issue = [&](int kt) {
 #pragma unroll
     for (int u = 0; u < ACH; ++u) {
@@ -599,16 +614,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       const int prow = e / (BN / 8), ch = e % (BN / 8);
       const int p = kt * 32 + prow;
       bool ok = (e < 32 * (BN / 8)) && p < P && (c0 + ch * 8) < a.C;
-      const int pp = ok ? p : 0;
-      const int n = pp / (a.Ho * a.Wo);
-      const int rem = pp - n * a.Ho * a.Wo;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
-      const int hi = ho * a.stride - a.pad + r;
-      const int wi = wo * a.stride - a.pad + s;
+      const int hi = g_ho[u] * a.stride - a.pad + r;
+      const int wi = g_wo[u] * a.stride - a.pad + s;
       ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-      rb[u] = ok ? *(const uint4*)(a.x + (((size_t)n * a.H + hi) * a.W + wi) * a.C + c0 + ch * 8)
+      rb[u] = ok ? *(const uint4*)(a.x + (((size_t)g_n[u] * a.H + hi) * a.W + wi) * a.C + c0 + ch * 8)
                  : make_uint4(0, 0, 0, 0);
+      g_wo[u] += 32;
+      while (g_wo[u] >= a.Wo) {
+        g_wo[u] -= a.Wo;
+        if (++g_ho[u] >= a.Ho) {
+          g_ho[u] = 0;
+          ++g_n[u];
+        }
+      }
     }
   };
   auto stage = [&](int buf) {
@@ -756,6 +774,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
     return VLSFR_OK;
   }
+  if (name && !strcmp(name, "wgrad_target_wgs")) {
+    g_wgrad_target = value > 0 ? value : 1024;
+    return VLSFR_OK;
+  }
   if (name && !strcmp(name, "bn_block_kb")) {
     extern int g_bn_block_bytes;
     g_bn_block_bytes = value > 0 ? value * 1024 : 65536;
@@ -877,8 +899,8 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   const int BM = d->Cout >= 128 ? 128 : 64;
   a.n_coltiles = (d->Cin + BN - 1) / BN;
   const int tiles = a.n_coltiles * d->R * d->S * ((d->Cout + BM - 1) / BM);
-  if (splitk <= 0) {   // aim at ~1024 workgroups, at least 8 k-tiles each
-    splitk = (1024 + tiles - 1) / tiles;
+  if (splitk <= 0) {   // aim at g_wgrad_target workgroups (each adds its whole tile with fp32 atomics), >= 8 k-tiles each
+    splitk = (g_wgrad_target + tiles - 1) / tiles;
     if (splitk > nkt / 8) splitk = nkt / 8;
     if (splitk < 1) splitk = 1;
   }
