@@ -450,6 +450,8 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
   float* dp = (float*)smem;                     // [D] accumulated gradient of this row
   float* red = dp + ((D + 3) & ~3);             // [16] scratch
   float* wts = red + 16;                        // [max(n_chunks, n_special)] per-chunk / per-special weights
+  const int nw_lds = a.n_chunks > a.n_special ? a.n_chunks : a.n_special;
+  const float** vptr = (const float**)(wts + ((nw_lds + 1) & ~1));   // [n_special] class-vector address per special column
   const int label = a.pool_label[i];
   const float qs = a.scale * LOG2E;
   for (int d = tid; d < D; d += 256) dp[d] = 0.f;
@@ -551,12 +553,15 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
         float w = exp2f(c * qs - M) * gscale * fac;
         if (s == st) w -= a.scale * inv_pos * dtm;
         wts[s] = w;
+        vptr[s] = special_vec(a.g, a.queue, a.Q, D, a.special_col[s], src[s]);
       }
       __syncthreads();
-      for (int s = 0; s < a.n_special; ++s) {
-        const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[s], src[s]);
-        const float w = wts[s];
-        for (int d = tid; d < D; d += 256) dp[d] += w * vec[d];
+      // thread per feature, loop over the special columns: weights and addresses come from LDS, so the
+      // global loads of consecutive columns are independent and stay in flight together
+      for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < a.n_special; ++s) acc += wts[s] * vptr[s][d];
+        dp[d] += acc;
       }
       __syncthreads();
     }
@@ -659,6 +664,8 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
   const int D = a.D;
   float* red = (float*)smem;                    // [16]
   float* wts = red + 16;                        // [max(n_chunks, n_special)]
+  const int nw_lds = a.n_chunks > a.n_special ? a.n_chunks : a.n_special;
+  const float** vptr = (const float**)(wts + ((nw_lds + 1) & ~1));   // [n_special]
   const int label = a.pool_label[i];
   const float qs = a.scale * LOG2E;
   const int lo = sa.slot_lo, hi = sa.slot_lo + (int)a.Q;
@@ -728,14 +735,17 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
         T[d] = 0.f;
       }
       __syncthreads();
-      for (int s = tid; s < a.n_special; s += 256)
-        wts[s] = owned(s) ? exp2f((s == st ? tm : cs[s]) * qs - M) * (s == st ? dtm : 1.f) : 0.f;
+      for (int s = tid; s < a.n_special; s += 256) {
+        const bool own = owned(s);
+        wts[s] = own ? exp2f((s == st ? tm : cs[s]) * qs - M) * (s == st ? dtm : 1.f) : 0.f;
+        // columns of other ranks get weight 0 and a harmless in-range address (their g row or slot 0)
+        vptr[s] = special_vec(a.g, a.queue, a.Q, D, own ? a.special_col[s] - lo : 0, own ? src[s] : -1);
+      }
       __syncthreads();
-      for (int s = 0; s < a.n_special; ++s) {
-        const float w = wts[s];
-        if (w == 0.f) continue;
-        const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[s] - lo, src[s]);
-        for (int d = tid; d < D; d += 256) O[d] += w * vec[d];
+      for (int d = tid; d < D; d += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < a.n_special; ++s) acc += wts[s] * vptr[s][d];
+        O[d] += acc;
       }
       if (st >= 0) {
         const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[st] - lo, src[st]);
@@ -1086,7 +1096,12 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   f.row_loss = row_loss;
   f.dP = dP;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
-  const size_t lds = ((size_t)((D + 3) & ~3) + 16 + nw) * 4;
+  const size_t lds = ((size_t)((D + 3) & ~3) + 16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + 16;
+  if (lds > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish: too many special columns for one LDS image");
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)head_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_fail(e, "head_finish: hipFuncSetAttribute");
+  }
   hipLaunchKernelGGL(head_finish_kernel, dim3(B), dim3(256), lds, st, f);
   VLSFR_HIP_CHECK_LAUNCH("head_finish launch");
   hipLaunchKernelGGL(head_loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, 2 * B, loss_out);
@@ -1188,7 +1203,14 @@ int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const fl
   sf.cand_val = cand_val;
   sf.cand_col = cand_col;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
-  hipLaunchKernelGGL(head_finish_shard_kernel, dim3(B), dim3(256), (size_t)(16 + nw) * 4, st, sf);
+  const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + 16;
+  if (lds_f > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish_shard: too many special columns for one LDS image");
+  if (lds_f > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)head_finish_shard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_f);
+    if (e != hipSuccess) return hip_fail(e, "head_finish_shard: hipFuncSetAttribute");
+  }
+  hipLaunchKernelGGL(head_finish_shard_kernel, dim3(B), dim3(256), lds_f, st, sf);
   VLSFR_HIP_CHECK_LAUNCH("head_finish_shard launch");
   return VLSFR_OK;
 }
