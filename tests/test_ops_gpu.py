@@ -185,7 +185,7 @@ def test_bn_nchw_flatten_output_and_gradient():
     dy_rows = dy.permute(0, 2, 1).reshape(M, C).contiguous()
     dx_b = ops.bn_backward(dy_rows.cuda().to(torch.bfloat16), xg, M, C, HW, mean, invstd, gamma.cuda(), beta.cuda(),
                            dgamma=dg[2], dbeta=dg[3])
-    assert torch.equal(dx_a, dx_b)
+    close(dx_a, dx_b.cpu(), 1e-2)     # same math; the atomic reduction order differs, so only to one bf16 ulp
     close(dg[0], dg[2].cpu(), 1e-5)
 
 
