@@ -37,7 +37,8 @@ struct ProfRec {
 bool g_prof_on = false;
 #define VLSFR_DEFAULT_CONV_VARIANT 3
 int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;
-int g_wgrad_target = 1024;   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
+int g_wgrad_target = 1024;
+int g_wgrad_kt = 32;   // pixels per k-tile of the weight-gradient kernel (32 or 64)   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -524,8 +525,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
       }
     }
   }
-  if (a.stats) {   // fused BatchNorm statistics: reduce over the 16 pixel lanes, one atomic per channel and wave
-    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
+  if (a.stats) {
+    // fused BatchNorm statistics: 16 pixel lanes -> one value per channel and wave (shuffles), the
+    // waves of the workgroup meet in LDS (the pipeline stages are free now), then ONE global atomic
+    // per channel and workgroup, issued as whole 256-byte wave-instructions
+    __syncthreads();
+    float* red = (float*)smem;   // [2][BM]
+    for (int i = tid; i < 2 * BM; i += NW * 64) red[i] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -536,12 +543,18 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
           s += __shfl_xor(s, o, 64);
           q += __shfl_xor(q, o, 64);
         }
-        const int m = m0 + wm * (BM / WM) + i * 16 + 4 * h + e;
-        if (r16 == 0 && m < a.Mrows) {
-          atomicAdd(dst + m, s);
-          atomicAdd(dst + a.Mrows + m, q);
+        const int ml = wm * (BM / WM) + i * 16 + 4 * h + e;
+        if (r16 == 0) {
+          atomicAdd(&red[ml], s);
+          atomicAdd(&red[BM + ml], q);
         }
       }
+    __syncthreads();
+    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
+    for (int i = tid; i < 2 * BM; i += NW * 64) {
+      const int k = i / BM, ml = i - k * BM;
+      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, red[i]);
+    }
   }
 }
 
@@ -557,17 +570,17 @@ struct WgradArgs {
   int n_coltiles;    // column tiles per tap = ceil(C / BN)
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int KT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int MT = BM / 32;
   constexpr int NT = BN / 32;
   constexpr int RSA = BM * 2 + 32;   // LDS row strides (bytes): +32 keeps the transposed reads conflict-free
   constexpr int RSB = BN * 2 + 32;
-  constexpr int ACH = 32 * (BM / 8) / 256 > 0 ? 32 * (BM / 8) / 256 : 1;   // 16-byte chunks per thread
-  constexpr int BCH = 32 * (BN / 8) / 256 > 0 ? 32 * (BN / 8) / 256 : 1;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 32 * (RSA + RSB)];
+  constexpr int ACH = KT * (BM / 8) / 256 > 0 ? KT * (BM / 8) / 256 : 1;   // 16-byte chunks per thread (KT pixels per k-tile)
+  constexpr int BCH = KT * (BN / 8) / 256 > 0 ? KT * (BN / 8) / 256 : 1;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * (RSA + RSB)];
   char* sA = smem;
-  char* sB = smem + 2 * 32 * RSA;
+  char* sB = smem + 2 * KT * RSA;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -578,7 +591,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const int tap = blockIdx.x / a.n_coltiles;
   const int c0 = (blockIdx.x - tap * a.n_coltiles) * BN;
   const int r = tap / a.S, s = tap - r * a.S;
-  const int nkt = (P + 31) / 32;
+  const int nkt = (P + KT - 1) / KT;
   const int per = (nkt + a.splitk - 1) / a.splitk;
   const int kt0 = blockIdx.z * per;
   const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   for (int u = 0; u < BCH; ++u) {
     const int e = tid + 256 * u;
     const int prow = e / (BN / 8);
-    const int64_t p = (int64_t)kt0 * 32 + prow;
+    const int64_t p = (int64_t)kt0 * KT + prow;
     const int64_t pc = p < P ? p : (P > 0 ? P - 1 : 0);
     g_n[u] = (int)(pc / (a.Ho * a.Wo));
     const int rem = (int)(pc - (int64_t)g_n[u] * a.Ho * a.Wo);
@@ -604,22 +617,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int u = 0; u < ACH; ++u) {
       const int e = tid + 256 * u;
       const int prow = e / (BM / 8), ch = e % (BM / 8);
-      const int p = kt * 32 + prow;
-      const bool ok = (e < 32 * (BM / 8)) && p < P && (m0 + ch * 8) < a.Cout;
+      const int p = kt * KT + prow;
+      const bool ok = (e < KT * (BM / 8)) && p < P && (m0 + ch * 8) < a.Cout;
       ra[u] = ok ? *(const uint4*)(a.dy + (size_t)p * a.Cout + m0 + ch * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < BCH; ++u) {
       const int e = tid + 256 * u;
       const int prow = e / (BN / 8), ch = e % (BN / 8);
-      const int p = kt * 32 + prow;
-      bool ok = (e < 32 * (BN / 8)) && p < P && (c0 + ch * 8) < a.C;
+      const int p = kt * KT + prow;
+      bool ok = (e < KT * (BN / 8)) && p < P && (c0 + ch * 8) < a.C;
       const int hi = g_ho[u] * a.stride - a.pad + r;
       const int wi = g_wo[u] * a.stride - a.pad + s;
       ok = ok && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
       rb[u] = ok ? *(const uint4*)(a.x + (((size_t)g_n[u] * a.H + hi) * a.W + wi) * a.C + c0 + ch * 8)
                  : make_uint4(0, 0, 0, 0);
-      g_wo[u] += 32;
+      g_wo[u] += KT;
       while (g_wo[u] >= a.Wo) {
         g_wo[u] -= a.Wo;
         if (++g_ho[u] >= a.Ho) {
@@ -633,12 +646,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int u = 0; u < ACH; ++u) {
       const int e = tid + 256 * u;
-      if (e < 32 * (BM / 8)) *(uint4*)(sA + buf * 32 * RSA + (e / (BM / 8)) * RSA + (e % (BM / 8)) * 16) = ra[u];
+      if (e < KT * (BM / 8)) *(uint4*)(sA + buf * KT * RSA + (e / (BM / 8)) * RSA + (e % (BM / 8)) * 16) = ra[u];
     }
 #pragma unroll
     for (int u = 0; u < BCH; ++u) {
       const int e = tid + 256 * u;
-      if (e < 32 * (BN / 8)) *(uint4*)(sB + buf * 32 * RSB + (e / (BN / 8)) * RSB + (e % (BN / 8)) * 16) = rb[u];
+      if (e < KT * (BN / 8)) *(uint4*)(sB + buf * KT * RSB + (e / (BN / 8)) * RSB + (e % (BN / 8)) * 16) = rb[u];
     }
   };
 
@@ -659,27 +672,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < kt1) issue(kt + 1);
-    bf16x8 fa[MT], fb[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      char* base = sA + buf * 32 * RSA + (wm * (BM / 2) + i * 16) * 2 + tcol;
-      short4v v0 = lds_read_tr16(base + trow * RSA);
-      short4v v1 = lds_read_tr16(base + (trow + 16) * RSA);
-      short __attribute__((ext_vector_type(8))) vs = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      fa[i] = __builtin_bit_cast(bf16x8, vs);
+    for (int kk = 0; kk < KT / 32; ++kk) {
+      bf16x8 fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        char* base = sA + buf * KT * RSA + kk * 32 * RSA + (wm * (BM / 2) + i * 16) * 2 + tcol;
+        short4v v0 = lds_read_tr16(base + trow * RSA);
+        short4v v1 = lds_read_tr16(base + (trow + 16) * RSA);
+        short __attribute__((ext_vector_type(8))) vs = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        fa[i] = __builtin_bit_cast(bf16x8, vs);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        char* base = sB + buf * KT * RSB + kk * 32 * RSB + (wn * (BN / 2) + j * 16) * 2 + tcol;
+        short4v v0 = lds_read_tr16(base + trow * RSB);
+        short4v v1 = lds_read_tr16(base + (trow + 16) * RSB);
+        short __attribute__((ext_vector_type(8))) vs = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        fb[j] = __builtin_bit_cast(bf16x8, vs);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
     }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      char* base = sB + buf * 32 * RSB + (wn * (BN / 2) + j * 16) * 2 + tcol;
-      short4v v0 = lds_read_tr16(base + trow * RSB);
-      short4v v1 = lds_read_tr16(base + (trow + 16) * RSB);
-      short __attribute__((ext_vector_type(8))) vs = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      fb[j] = __builtin_bit_cast(bf16x8, vs);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
     if (kt + 1 < kt1) stage(buf ^ 1);
     __syncthreads();
   }
@@ -772,6 +788,10 @@ void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad_kt")) {
+    g_wgrad_kt = value == 64 ? 64 : 32;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "wgrad_target_wgs")) {
@@ -893,7 +913,8 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   a.stride = d->stride;
   a.pad = d->pad;
   const int P = a.Nimg * a.Ho * a.Wo;
-  const int nkt = (P + 31) / 32;
+  const int KT = g_wgrad_kt;
+  const int nkt = (P + KT - 1) / KT;
   const bool wide = d->Cin >= 128;
   const int BN = wide ? 128 : 64;
   const int BM = d->Cout >= 128 ? 128 : 64;
@@ -908,10 +929,16 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   dim3 grid(a.n_coltiles * d->R * d->S, (d->Cout + BM - 1) / BM, splitk);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * d->R * d->S * d->Cin);
-  if (BM == 128 && BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
-  else if (BM == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
-  else if (BN == 128) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+#define VLSFR_WGRAD(BM_, BN_)                                                                           \
+  do {                                                                                                 \
+    if (KT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 64>), grid, dim3(256), 0, st, a);      \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 32>), grid, dim3(256), 0, st, a);               \
+  } while (0)
+  if (BM == 128 && BN == 128) VLSFR_WGRAD(128, 128);
+  else if (BM == 128) VLSFR_WGRAD(128, 64);
+  else if (BN == 128) VLSFR_WGRAD(64, 128);
+  else VLSFR_WGRAD(64, 64);
+#undef VLSFR_WGRAD
   VLSFR_HIP_CHECK_LAUNCH("conv_wgrad launch");
   return VLSFR_OK;
 }
