@@ -8,6 +8,8 @@ cin = cout = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 hw = int(sys.argv[4]) if len(sys.argv) > 4 else 14
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 20
 L = _lib.lib(); L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(variant))
+for kv in os.environ.get("OPTS", "").split():
+    k, v = kv.split("="); L.vlsfr_set_option(k.encode(), ctypes.c_int32(int(v)))
 x = torch.randn(B, hw, hw, cin, device="cuda").to(torch.bfloat16)
 w = (torch.randn(cout, 3, 3, cin, device="cuda") * 0.05).to(torch.bfloat16)
 d = ops.ConvDesc(B, hw, hw, cin, cout, 3, 3, 1, 1)

@@ -349,7 +349,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
   uint32_t b_mask[BI];
   {
     // pixel coordinates: one division for the first row of this lane, the other rows (RPI pixels
-    // further each) by carry; tap validity as the outer product of 3 row bits and 3 column bits
+    // further each) by carry; tap validity as the outer product of 3 row bits and 3 column bits,
+    // both in closed form (filters are at most 3 x 3)
     int p = p0 + wave * BI * RPI + rsub;
     const int HoWo = a.Ho * a.Wo;
     const int pc = p < P ? p : (P > 0 ? P - 1 : 0);
@@ -357,45 +358,30 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
     int rem = pc - n * HoWo;
     int ho = rem / a.Wo;
     int wo = rem - ho * a.Wo;
+    const uint32_t rbits = (1u << a.R) - 1u, sbits = (1u << a.S) - 1u;
+    const bool fwd = a.mode == 0, s2 = a.stride == 2;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const bool okp = p < P;
-      int bh, bw;
-      if (a.mode == 0) {
-        bh = ho * a.stride - a.pad;
-        bw = wo * a.stride - a.pad;
-      } else if (a.stride == 1) {
-        bh = ho + a.pad;
-        bw = wo + a.pad;
-      } else {
-        bh = (ho + a.pad) >> 1;
-        bw = (wo + a.pad) >> 1;
+      // tap r reads row  fwd: bh + r | input gradient, stride 1: bh - r | stride 2: bh - (r >> 1), only
+      // when (ho + pad - r) is even
+      const int th = ho + a.pad, tw = wo + a.pad;
+      const int bh = fwd ? ho * a.stride - a.pad : (s2 ? th >> 1 : th);
+      const int bw = fwd ? wo * a.stride - a.pad : (s2 ? tw >> 1 : tw);
+      uint32_t vh = 0, vw = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int dh = fwd ? r : (s2 ? -(r >> 1) : -r);
+        const bool par_h = fwd || !s2 || !((th - r) & 1);
+        const bool par_w = fwd || !s2 || !((tw - r) & 1);
+        vh |= (par_h && (unsigned)(bh + dh) < (unsigned)a.H) ? (1u << r) : 0u;
+        vw |= (par_w && (unsigned)(bw + dh) < (unsigned)a.W) ? (1u << r) : 0u;
       }
-      uint32_t vh = 0, vw = 0;   // bit r / s set when tap row r / column s reads inside the gathered tensor
-      for (int r = 0; r < a.R; ++r) {
-        int hi, wi;
-        bool okh = true, okw = true;
-        if (a.mode == 0) {
-          hi = bh + r;
-          wi = bw + r;
-        } else if (a.stride == 1) {
-          hi = bh - r;
-          wi = bw - r;
-        } else {
-          okh = !((ho + a.pad - r) & 1);
-          okw = !((wo + a.pad - r) & 1);
-          hi = bh - (r >> 1);
-          wi = bw - (r >> 1);
-        }
-        if (okh && hi >= 0 && hi < a.H) vh |= 1u << r;
-        if (okw && wi >= 0 && wi < a.W) vw |= 1u << r;
-      }
-      uint32_t mask = 0;
-      for (int r = 0; r < a.R; ++r)
-        if (vh & (1u << r)) mask |= vw << (r * a.S);
-      b_mask[i] = okp ? mask : 0u;
+      vh &= rbits;
+      vw &= sbits;
+      const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << a.S : 0u) | ((vh & 4u) ? vw << (2 * a.S) : 0u);
+      b_mask[i] = p < P ? mask : 0u;
       b_ptr[i] = a.x + (((int64_t)n * a.H + bh) * a.W + bw) * a.C + lchunk * 8;   // tap (0,0); only dereferenced when valid
-      // advance RPI pixels
+      // advance RPI pixels (one or two row carries on the feature maps, RPI of them on the 1 x 1 "image" of the FC)
       p += RPI;
       wo += RPI;
       while (wo >= a.Wo) {
@@ -408,10 +394,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
     }
   }
 
-  // k-tile cursor of the NEXT tile to issue, advanced incrementally (no divisions in the loop)
-  int is_k0 = kt0 * BK;
-  int is_tap = is_k0 / a.C;
-  int is_c0 = is_k0 - is_tap * a.C;
+  // k-tile cursor of the NEXT tile to issue, advanced incrementally (no divisions in the loop).
+  // Order: channel chunk outer, filter tap inner -- the R*S taps of one BK-channel chunk read the same
+  // 128-byte lines of the gathered tensor (shifted by a pixel / a row), so a workgroup's live footprint
+  // is one chunk of its pixels (+ halo) and stays in the CU's L1 / the XCD's L2 across the taps
+  // (L2 misses per launch fell 3x on the 256-channel 14x14 layer, rocprofv3 TCC_MISS).
+  const int ntap = a.R * a.S;
+  int is_c0 = (kt0 / ntap) * BK;
+  int is_tap = kt0 % ntap;
   int is_r = is_tap / a.S;
   int is_s = is_tap - is_r * a.S;
   auto issue = [&](int stage) {
@@ -420,6 +410,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
     else if (a.stride == 1) toff = -(is_r * a.W + is_s) * a.C;
     else toff = -((is_r >> 1) * a.W + (is_s >> 1)) * a.C;
     toff += is_c0;
+    const int is_k0 = is_tap * a.C + is_c0;   // column of the [Mrows][R*S*C] weight matrix
     const uint32_t bit = 1u << is_tap;
     char* st = smem + stage * STAGE;
 #pragma unroll
@@ -433,15 +424,14 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + BM * RSB + (wave * BI + i) * 1024), 16, 0,
                                        0);
     }
-    is_k0 += BK;
-    is_c0 += BK;
-    if (is_c0 >= a.C) {
-      is_c0 = 0;
-      ++is_tap;
-      if (++is_s >= a.S) {
-        is_s = 0;
-        ++is_r;
-      }
+    ++is_tap;
+    if (++is_s >= a.S) {
+      is_s = 0;
+      ++is_r;
+    }
+    if (is_tap >= ntap) {
+      is_tap = is_r = is_s = 0;
+      is_c0 += BK;
     }
   };
 
@@ -491,20 +481,17 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
-  float cs[MT][4], cq[MT][4];
+  const int mw = m0 + wm * (BM / WM) + 4 * h;     // + 16 i
+  const int pw = p0 + wn * (BN / WN) + r16;       // + 16 j
+  if (a.out_f32) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) {
+      const int p = pw + j * 16;
+      if (p >= P) continue;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int p = p0 + wn * (BN / WN) + j * 16 + r16;
-    if (p >= P) continue;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * (BM / WM) + i * 16 + 4 * h;
-      if (m >= a.Mrows) continue;
-      if (a.out_f32) {
+      for (int i = 0; i < MT; ++i) {
+        const int m = mw + i * 16;
+        if (m >= a.Mrows) continue;
         float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
         if (a.splitk > 1) {
 #pragma unroll
@@ -512,48 +499,69 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
         } else {
           *(f32x4*)dst = acc[i][j];
         }
-      } else {
+      }
+    }
+    return;
+  }
+  // bf16 output; the BatchNorm statistics are taken from the ROUNDED values (what the consumer reads)
+  float cs[MT][4], cq[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
+  u16* yrow = (u16*)a.y + (size_t)pw * a.Mrows + mw;
+  auto store = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const bool okp = FULL || pw + j * 16 < P;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bool ok = okp && (FULL || mw + i * 16 < a.Mrows);
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           o[e] = (__bf16)acc[i][j][e];
-          const float f = (float)o[e];
+          const float f = ok ? (float)o[e] : 0.f;
           cs[i][e] += f;
           cq[i][e] += f * f;
         }
-        *(bf16x4*)((u16*)a.y + (size_t)p * a.Mrows + m) = o;
+        if (ok) *(bf16x4*)(yrow + (size_t)j * 16 * a.Mrows + i * 16) = o;
       }
     }
-  }
+  };
+  if (p0 + BN <= P && m0 + BM <= a.Mrows) store(std::true_type{});
+  else store(std::false_type{});
   if (a.stats) {
-    // fused BatchNorm statistics: 16 pixel lanes -> one value per channel and wave (shuffles), the
-    // waves of the workgroup meet in LDS (the pipeline stages are free now), then ONE global atomic
-    // per channel and workgroup, issued as whole 256-byte wave-instructions
-    __syncthreads();
-    float* red = (float*)smem;   // [2][BM]
-    for (int i = tid; i < 2 * BM; i += NW * 64) red[i] = 0.f;
-    __syncthreads();
+    // fused BatchNorm statistics: the 16 pixel lanes of a row are summed with DPP adds (no LDS
+    // round trips), lane r16 of row h keeps channel 16 (r16 >> 2) + 4h + (r16 & 3); the WN pixel
+    // halves of the workgroup meet in the LDS stage the last k-tile did not use (its readers all
+    // passed the last barrier), then ONE global atomic per channel and workgroup.
+    float sv = 0.f, qv = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float s = cs[i][e], q = cq[i][e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s += __shfl_xor(s, o, 64);
-          q += __shfl_xor(q, o, 64);
-        }
-        const int ml = wm * (BM / WM) + i * 16 + 4 * h + e;
-        if (r16 == 0) {
-          atomicAdd(&red[ml], s);
-          atomicAdd(&red[BM + ml], q);
+        const float s = row16_sum(cs[i][e]), q = row16_sum(cq[i][e]);
+        if (r16 == i * 4 + e) {
+          sv = s;
+          qv = q;
         }
       }
+    float* red = (float*)(smem + (nk % NST) * STAGE);   // [WN][2][BM]
+    if (r16 < MT * 4) {
+      const int ml = wm * (BM / WM) + (r16 >> 2) * 16 + 4 * h + (r16 & 3);
+      red[(wn * 2 + 0) * BM + ml] = sv;
+      red[(wn * 2 + 1) * BM + ml] = qv;
+    }
     __syncthreads();
     float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
     for (int i = tid; i < 2 * BM; i += NW * 64) {
       const int k = i / BM, ml = i - k * BM;
-      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, red[i]);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) v += red[(w * 2 + k) * BM + ml];
+      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, v);
     }
   }
 }

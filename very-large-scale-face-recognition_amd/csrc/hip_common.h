@@ -29,6 +29,20 @@ __device__ __forceinline__ short4v lds_read_tr16(void* lds_addr) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((VLSFR_LDS short4v*)lds_addr);
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16h .. 16h + 15), result in every lane of the row:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- four VALU adds, no LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
