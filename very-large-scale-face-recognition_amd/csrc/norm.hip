@@ -335,9 +335,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
     sh[C + c] = s0 * invM;
     sh[2 * C + c] = s1 * invM;
     if (blockIdx.x == 0) {
-      if (a.dbeta) a.dbeta[c] += s0;
-      if (a.dgamma) a.dgamma[c] += s1;
-      if (a.dslope && a.slope) a.dslope[c] += s2;
+      // atomics: the two backward passes of a step may run concurrently on two streams (model/_native.py)
+      if (a.dbeta) atomicAdd(&a.dbeta[c], s0);
+      if (a.dgamma) atomicAdd(&a.dgamma[c], s1);
+      if (a.dslope && a.slope) atomicAdd(&a.dslope[c], s2);
     }
   }
   __syncthreads();
@@ -512,8 +513,8 @@ __global__ void embed_bn_bwd_kernel(EmbedBwdArgs a) {
     s0 += dzv;
     s1 += dzv * a.xhat[(size_t)b * a.D + d];
   }
-  a.dbeta[d] += s0;
-  if (a.dgamma) a.dgamma[d] += s1;
+  atomicAdd(&a.dbeta[d], s0);
+  if (a.dgamma) atomicAdd(&a.dgamma[d], s1);
   const float k = g * a.invstd[d];
   const float m0 = g * s0 / a.B, m1 = g * s1 / a.B;
   float sb = 0.f;
@@ -524,7 +525,7 @@ __global__ void embed_bn_bwd_kernel(EmbedBwdArgs a) {
     a.dfc[i] = f2bf(dv);
     sb += dv;
   }
-  if (a.dfc_bias) a.dfc_bias[d] += sb;
+  if (a.dfc_bias) atomicAdd(&a.dfc_bias[d], sb);
 }
 
 // ---------------------------------------------------------------------------------------------

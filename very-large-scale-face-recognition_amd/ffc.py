@@ -77,19 +77,37 @@ class FFC(Module):
         ema_update(list(self.gallery_net.parameters()), list(self.probe_net.parameters()), self.m)
         self.gallery_net.weights_dirty = True
 
+    def embed_pair(self, p_data, g_data, update_gallery):
+        """p = probe_net(p_data) (autograd) and g = gallery_net(g_data) (no grad), the two backbones of one
+        pass (ffc.py:156-161 / :211-217).  They share nothing but the input batch, so the gallery pass runs
+        on a second HIP stream beside the probe pass: the tail of every kernel of one net (a 14x14 layer
+        fills 1.5 waves of workgroups) is covered by the kernels of the other.  The EMA of the rollback pass
+        reads only probe PARAMETERS, which the probe forward does not change, so doing it first is the
+        reference order's result."""
+        main = torch.cuda.current_stream()
+        side = self.__dict__.get('_side_stream')
+        if side is None or side.device != main.device:
+            side = torch.cuda.Stream(device=main.device)
+            self.__dict__['_side_stream'] = side
+        with torch.no_grad():
+            if update_gallery:
+                self._momentum_update_gallery()
+            side.wait_stream(main)                       # inputs and the EMA'd weights are ready
+            with torch.cuda.stream(side):
+                g = self.gallery_net(g_data)
+        p = self.probe_net(p_data)
+        main.wait_stream(side)
+        g.record_stream(main)
+        return p, g
+
     def forward_impl(self, p_data, g_data, probe_label, gallery_label):          # ffc.py:153-204
         head = self._ensure_head()
-        p = self.probe_net(p_data)
-        with torch.no_grad():
-            g = self.gallery_net(g_data)
+        p, g = self.embed_pair(p_data, g_data, update_gallery=False)
         return head.run_pass(p, g, probe_label, gallery_label, transactional=False)
 
     def forward_impl_rollback(self, p_data, g_data, probe_label, gallery_label):  # ffc.py:208-260
         head = self._ensure_head()
-        p = self.probe_net(p_data)
-        with torch.no_grad():
-            self._momentum_update_gallery()
-            g = self.gallery_net(g_data)
+        p, g = self.embed_pair(p_data, g_data, update_gallery=True)
         return head.run_pass(p, g, probe_label, gallery_label, transactional=True)
 
     def forward(self, x, y, x_label, y_label):                        # ffc.py:264-267

@@ -22,21 +22,43 @@ def _stream():
 
 
 class _BackboneFn(torch.autograd.Function):
-    """One node for the whole backbone: forward = vlsfr_iresnet_forward, backward =
-    vlsfr_iresnet_backward, which accumulates straight into the parameters' .grad buffers."""
+    """One node for the whole backbone: forward = <prefix>_forward, backward = <prefix>_backward, which
+    accumulates straight into the parameters' .grad buffers (atomically, so that the backward passes of
+    the two forward passes of an FFC step can run side by side: every second one goes to a second HIP
+    stream with its own scratch, and the autograd engine's end-of-backward callback joins it)."""
 
     @staticmethod
     def forward(ctx, x, net, *params):
         emb, ws = net._run_forward(x, save=True)
         ctx.net, ctx.ws, ctx.B = net, ws, x.shape[0]
+        ctx.slot = net._fwd_slot
+        net._fwd_slot ^= 1
         return emb
 
     @staticmethod
     def backward(ctx, demb):
-        ctx.net._run_backward(demb.contiguous().float(), ctx.ws, ctx.B)
-        ctx.ws = None
-        return (None, None) + (None,) * len(ctx.net._plist)
+        net = ctx.net
+        demb = demb.contiguous().float()
+        if ctx.slot == 1 and net.concurrent_backward:
+            main = torch.cuda.current_stream()
+            side = net._side_stream(main.device)
+            net._ensure_grads()                         # allocate / zero missing .grad on the main stream
+            side.wait_stream(main)                      # demb and everything before it
+            with torch.cuda.stream(side):
+                net._run_backward(demb, ctx.ws, ctx.B, alt=True)
+            demb.record_stream(side)
+            ctx.ws.record_stream(side)
+            if not net._join_queued:
+                net._join_queued = True
 
+                def join():
+                    net._join_queued = False
+                    torch.cuda.current_stream().wait_stream(side)
+                torch.autograd.Variable._execution_engine.queue_callback(join)
+        else:
+            net._run_backward(demb, ctx.ws, ctx.B)
+        ctx.ws = None
+        return (None, None) + (None,) * len(net._plist)
 
 
 class NativeBackbone(nn.Module):
@@ -51,7 +73,12 @@ class NativeBackbone(nn.Module):
         self._wcache = None
         self._w_sig = None
         self._scratch = None
+        self._scratch_alt = None
         self._eval_ctx = None
+        self._fwd_slot = 0
+        self._join_queued = False
+        self._bwd_stream = None
+        self.concurrent_backward = True
         self._nbt_pending = 0
         self.weights_dirty = True
 
@@ -70,6 +97,11 @@ class NativeBackbone(nn.Module):
 
     def _create(self, L, B, h):
         raise NotImplementedError
+
+    def _side_stream(self, device):
+        if self._bwd_stream is None or self._bwd_stream.device != device:
+            self._bwd_stream = torch.cuda.Stream(device=device)
+        return self._bwd_stream
 
     # ------------------------------------------------------------------------------------------
     @property
@@ -157,12 +189,10 @@ class NativeBackbone(nn.Module):
         self._keep = x
         return emb, ws
 
-    def _run_backward(self, demb, ws, B):
-        L = _lib.lib()
-        h, sizes = self._handle(B, demb.device)
-        params, _ = self._tables()
+    def _ensure_grads(self):
+        """.grad buffers in the executor's layout (allocated + zeroed on the CURRENT stream when missing)."""
         grads = []
-        for p in params:
+        for p in self._plist:
             if not p.requires_grad:
                 grads.append(None)
                 continue
@@ -171,11 +201,23 @@ class NativeBackbone(nn.Module):
             elif p.dim() == 4 and not p.grad.permute(0, 2, 3, 1).is_contiguous():
                 p.grad = p.grad.contiguous(memory_format=torch.channels_last)
             grads.append(p.grad)
+        return grads
+
+    def _run_backward(self, demb, ws, B, alt=False):
+        L = _lib.lib()
+        h, sizes = self._handle(B, demb.device)
+        scratch = self._scratch
+        if alt:                                        # second scratch for the pass on the side stream
+            if self._scratch_alt is None or self._scratch_alt.numel() < sizes[2] or self._scratch_alt.device != demb.device:
+                self._scratch_alt = torch.empty(sizes[2], dtype=torch.uint8, device=demb.device)
+            scratch = self._scratch_alt
+        params, _ = self._tables()
+        grads = self._ensure_grads()
         bwd = getattr(L, self._cprefix + "_backward")
         bwd.restype = ctypes.c_int
         _lib.check(bwd(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
                        ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                       ctypes.c_void_p(self._scratch.data_ptr()), _stream()), self._cprefix + "_backward")
+                       ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward")
 
     def forward(self, x):
         # Training mode always (the reference never calls .eval(), ffc.py:22-23); eval() only stops

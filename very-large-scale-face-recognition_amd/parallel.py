@@ -56,11 +56,8 @@ class DataParallelFFC(object):
     def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
         m = self.m
         head = m._ensure_head()
-        p = m.probe_net(p_data)
+        p, g = m.embed_pair(p_data, g_data, update_gallery=transactional)
         with torch.no_grad():
-            if transactional:
-                m._momentum_update_gallery()
-            g = m.gallery_net(g_data)
             g_all = self._gather_rows(g)
         pl = self._gather_labels(probe_label)
         gl = self._gather_labels(gallery_label)
@@ -150,11 +147,8 @@ class ShardedFFC(DataParallelFFC):
     def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
         from .head import _HeadFn
         m = self.m
-        p = m.probe_net(p_data)
+        p, g = m.embed_pair(p_data, g_data, update_gallery=transactional)
         with torch.no_grad():
-            if transactional:
-                m._momentum_update_gallery()
-            g = m.gallery_net(g_data)
             g_all = self._gather_rows(g)
             p_all = self._gather_rows(p.detach())
         pl = self._gather_labels(probe_label)
