@@ -285,12 +285,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 //     with (row & 7).  An LDS-DMA wave-instruction writes 1 KiB linearly (8 rows x 8 chunks), so the
 //     swizzle is applied to the per-lane SOURCE address: lane (r = lane >> 3, c = lane & 7) fetches
 //     logical chunk c ^ r of its row.
-//   * padding / out-of-range rows read a 16-byte zero page instead (the DMA always writes its lanes).
+//   * both operands go through raw buffer descriptors (buffer_load_dwordx4 ... lds): padding and
+//     out-of-range rows carry an out-of-range offset, for which the DMA writes zeros.
 //   * fragment reads are inline-asm ds_read_b128 behind an explicit lgkmcnt(0): the compiler cannot
 //     see that they touch the DMA'd bytes, so it inserts no vmcnt(0) in front of them.
 // ------------------------------------------------------------------------------------------------
-__device__ uint4 g_zero_page[4] = {};
-
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
@@ -307,6 +306,7 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
 
 template <int BM, int BN, int BK, int NST, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only
   // wave grid WM x WN (NW waves): each wave keeps (BM / WM) x (BN / WN) of the tile; the 8-wave
   // 256 x 128 / 128 x 256 tiles raise the FLOPs per byte a CU has to pull from L2 by a third over
   // the 4-wave 128 x 128 tile (the per-CU load path, not HBM, is what bounds this kernel)
@@ -338,14 +338,21 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
   // ---- per-lane gather descriptors
   const int rsub = lane / CPR;
   const int lchunk = (lane % CPR) ^ swz<BK>(rsub);   // logical 16-byte chunk this lane fetches
-  const u16* zero = (const u16*)g_zero_page;
-  const u16* a_ptr[AI];
+  // Both operands are fetched through raw buffer descriptors: a lane whose row / tap is padding gets
+  // the offset 0x80000000, which is out of range for every tensor this path accepts (< 2 GiB), and the
+  // LDS-DMA writes zeros for it (scripts/probes/buf_lds_oob.hip) -- no zero page, 32-bit offsets.
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Mrows * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.Nimg * a.H * a.W * a.C * 2), 0x00020000);
+  int a_off[AI];   // byte offset of this lane's chunk in column 0 of its weight row
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + (wave * AI + i) * RPI + rsub;
-    a_ptr[i] = m < a.Mrows ? a.w + (size_t)m * K + lchunk * 8 : nullptr;
+    a_off[i] = m < a.Mrows ? (m * K + lchunk * 8) * 2 : OOB;
   }
-  const u16* b_ptr[BI];
+  int b_off[BI];   // byte offset of tap (0,0), channel chunk 0 (may be negative: only used with a valid tap)
   uint32_t b_mask[BI];
   {
     // pixel coordinates: one division for the first row of this lane, the other rows (RPI pixels
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
       vw &= sbits;
       const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << a.S : 0u) | ((vh & 4u) ? vw << (2 * a.S) : 0u);
       b_mask[i] = p < P ? mask : 0u;
-      b_ptr[i] = a.x + (((int64_t)n * a.H + bh) * a.W + bw) * a.C + lchunk * 8;   // tap (0,0); only dereferenced when valid
+      b_off[i] = ((((n * a.H + bh) * a.W + bw) * a.C) + lchunk * 8) * 2;
       // advance RPI pixels (one or two row carries on the feature maps, RPI of them on the 1 x 1 "image" of the FC)
       p += RPI;
       wo += RPI;
@@ -414,15 +421,13 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
     const uint32_t bit = 1u << is_tap;
     char* st = smem + stage * STAGE;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const u16* src = a_ptr[i] ? a_ptr[i] + is_k0 : zero;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + (wave * AI + i) * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(st + (wave * AI + i) * 1024), 16, a_off[i], is_k0 * 2, 0,
+                                               0);
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const u16* src = (b_mask[i] & bit) ? b_ptr[i] + toff : zero;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(st + BM * RSB + (wave * BI + i) * 1024), 16, 0,
-                                       0);
+      const int off = (b_mask[i] & bit) ? b_off[i] + toff * 2 : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + BM * RSB + (wave * BI + i) * 1024), 16, off, 0, 0, 0);
     }
     ++is_tap;
     if (++is_s >= a.S) {
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
       if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, v);
     }
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -765,7 +771,8 @@ int run_igemm(ConvArgs a, hipStream_t st) {
   ProfScope prof(st, 0, 2.0 * P * (double)a.Mrows * a.R * a.S * a.C);
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
-  const bool glds_ok = g_use_glds && a.C % 64 == 0 && a.R * a.S <= 9 && (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 31);
+  const bool glds_ok = g_use_glds && a.C % 64 == 0 && a.R * a.S <= 9 && (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30) &&
+                       (size_t)a.Mrows * a.R * a.S * a.C < (1ull << 30);
   if (glds_ok) {
     int rc;
     const bool big = a.Mrows >= 128;
