@@ -186,15 +186,19 @@ def main():
     L.vlsfr_profile_enable(1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_ms = []
     for i in range(args.steps):
+        th = time.perf_counter()
         loss = one_step(args.warmup + i)
+        host_ms.append((time.perf_counter() - th) * 1e3)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     L.vlsfr_profile_enable(0)
-    note("timed region done: %.3f s for %d steps" % (dt, args.steps))
+    note("timed region done: %.3f s for %d steps; host-side issue time per step (ms): %s" %
+         (dt, args.steps, " ".join("%.1f" % v for v in host_ms)))
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

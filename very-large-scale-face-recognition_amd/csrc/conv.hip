@@ -38,7 +38,8 @@ bool g_prof_on = false;
 #define VLSFR_DEFAULT_CONV_VARIANT 3
 int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;
 int g_wgrad_target = 1024;
-int g_wgrad_kt = 32;   // pixels per k-tile of the weight-gradient kernel (32 or 64)   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
+int g_wgrad_kt = 32;
+int g_wgrad_glds = 1;   // 1: LDS-DMA ring (conv_wgrad_glds_kernel), 0: register-staged kernel   // pixels per k-tile of the weight-gradient kernel (32 or 64)   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -730,6 +731,212 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad_glds_kernel -- the weight gradient with the same LDS-DMA ring as the forward kernel.
+// The register-staged kernel above keeps ONE 32-pixel k-tile in flight per workgroup and waits a full
+// memory latency per 16 MFMAs; here KT = 64 pixels per stage, NST stages, both operands through raw
+// buffer descriptors (rows past P and padded taps are out-of-range offsets -> zero fill).
+//   * LDS image per stage: A [KT pixels][BM channels], B [KT pixels][BN channels] bf16, unpadded rows;
+//     the 32-byte blocks (16 channels) of a row are XOR-swizzled with the pixel row so that the
+//     ds_read_b64_tr_b16 of a 32-lane group (8 rows x 32 bytes) covers all 64 banks once.  The DMA writes
+//     1 KiB linearly, so the swizzle is applied to the per-lane SOURCE chunk.
+//   * the gathered operand's pixel coordinates advance by KT pixels per k-tile with precomputed
+//     (images, rows, columns) steps and two carries -- no divisions in the loop.
+// ------------------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ short4v lds_read_tr_asm(uint32_t addr) {
+  short4v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+template <int ROWB>
+__device__ __forceinline__ int wg_swz(int row) {   // 32-byte block permutation of a ROWB-byte row
+  if constexpr (ROWB >= 256) return row & 7;
+  else return (row >> 1) & 3;
+}
+
+template <int BM, int BN, int KT, int NST>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int MT = BM / 32, NT = BN / 32;
+  constexpr int RA = BM * 2, RB = BN * 2;            // row bytes
+  constexpr int RPIA = 1024 / RA, RPIB = 1024 / RB;  // pixel rows per 1-KiB DMA wave-instruction
+  constexpr int AI = KT / (4 * RPIA), BI = KT / (4 * RPIB);
+  constexpr int STAGE = KT * (RA + RB);
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = a.Nimg * a.Ho * a.Wo;
+  const int m0 = blockIdx.y * BM;
+  const int tap = blockIdx.x / a.n_coltiles;
+  const int c0 = (blockIdx.x - tap * a.n_coltiles) * BN;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
+  const int nkt = (P + KT - 1) / KT;
+  const int per = (nkt + a.splitk - 1) / a.splitk;
+  const int kt0 = blockIdx.z * per;
+  const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
+  const int nk = kt1 - kt0;
+  if (nk <= 0) return;
+
+  const __amdgpu_buffer_rsrc_t rs_dy =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)P * a.Cout * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.Nimg * a.H * a.W * a.C * 2), 0x00020000);
+
+  // ---- A (dy): lane -> (row in instruction, physical chunk); offset linear in the pixel index
+  int a_off[AI];
+  {
+    const int rin = lane / (RA / 16), pc = lane % (RA / 16);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = (wave * AI + i) * RPIA + rin;
+      const int lc = (((pc >> 1) ^ wg_swz<RA>(row)) << 1) | (pc & 1);
+      a_off[i] = (m0 + lc * 8 < a.Cout) ? (row * a.Cout + m0 + lc * 8) * 2 : OOB;
+    }
+  }
+  // ---- B (x, gathered at this workgroup's tap): per-instruction pixel coordinates
+  int b_n[BI], b_h[BI], b_w[BI], b_c[BI];
+  const int HoWo = a.Ho * a.Wo;
+  const int dN = KT / HoWo, dRem = KT - dN * HoWo, dH = dRem / a.Wo, dW = dRem - dH * a.Wo;   // KT pixels as (images, rows, columns)
+  {
+    const int rin = lane / (RB / 16), pc = lane % (RB / 16);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = (wave * BI + i) * RPIB + rin;
+      const int lc = (((pc >> 1) ^ wg_swz<RB>(row)) << 1) | (pc & 1);
+      b_c[i] = (c0 + lc * 8 < a.C) ? (c0 + lc * 8) * 2 : OOB;
+      const int64_t p = (int64_t)kt0 * KT + row;     // may be >= P: n >= Nimg marks it
+      b_n[i] = (int)(p / HoWo);
+      const int rem = (int)(p - (int64_t)b_n[i] * HoWo);
+      b_h[i] = rem / a.Wo;
+      b_w[i] = rem - b_h[i] * a.Wo;
+    }
+  }
+  int a_soff = kt0 * KT * a.Cout * 2;
+  auto issue = [&](int stage) {
+    char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_dy, (lds_void_t*)(st + (wave * AI + i) * 1024), 16, a_off[i], a_soff, 0, 0);
+    a_soff += KT * a.Cout * 2;
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int hi = b_h[i] * a.stride - a.pad + tr;
+      const int wi = b_w[i] * a.stride - a.pad + ts;
+      const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && b_n[i] < a.Nimg;
+      const int off = ((b_n[i] * a.H + hi) * a.W + wi) * a.C * 2 + b_c[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + KT * RA + (wave * BI + i) * 1024), 16,
+                                               (ok && b_c[i] != OOB) ? off : OOB, 0, 0, 0);
+      // advance KT pixels
+      b_w[i] += dW;
+      const int c1 = b_w[i] >= a.Wo;
+      b_w[i] -= c1 ? a.Wo : 0;
+      b_h[i] += dH + c1;
+      const int c2 = b_h[i] >= a.Ho;
+      b_h[i] -= c2 ? a.Ho : 0;
+      b_n[i] += dN + c2;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed block reads: lane (q = r16 >> 2, p4 = r16 & 3) of group h addresses pixel row 4h + q
+  // (and + 16), bytes 8 p4 .. 8 p4 + 7 of a 32-byte block; k order = 16 (e >> 2) + 4h + (e & 3) on
+  // both operands.
+  const int trow = 4 * h + (r16 >> 2);
+  const int tcol = (r16 & 3) * 8;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  uint32_t rdA[MT], rdB[NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rdA[i] = lds0 + trow * RA + (((wm * MT + i) ^ wg_swz<RA>(trow)) << 5) + tcol;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) rdB[j] = lds0 + KT * RA + trow * RB + (((wn * NT + j) ^ wg_swz<RB>(trow)) << 5) + tcol;
+
+  const int pre = nk < NST - 1 ? nk : NST - 1;
+  for (int s = 0; s < pre; ++s) issue(s);
+
+  constexpr int KK = KT / 32;
+  for (int it = 0; it < nk; ++it) {
+    const int later = (nk - 1 - it) < (NST - 2) ? (nk - 1 - it) : (NST - 2);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + NST - 1 < nk) issue((it + NST - 1) % NST);
+    const uint32_t sb = (uint32_t)((it % NST) * STAGE);
+    short4v fa[KK][MT][2], fb[KK][NT][2];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        fa[kk][i][0] = kk == 0 ? lds_read_tr_asm<0>(rdA[i] + sb) : lds_read_tr_asm<32 * RA>(rdA[i] + sb);
+        fa[kk][i][1] = kk == 0 ? lds_read_tr_asm<16 * RA>(rdA[i] + sb) : lds_read_tr_asm<48 * RA>(rdA[i] + sb);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        fb[kk][j][0] = kk == 0 ? lds_read_tr_asm<0>(rdB[j] + sb) : lds_read_tr_asm<32 * RB>(rdB[j] + sb);
+        fb[kk][j][1] = kk == 0 ? lds_read_tr_asm<16 * RB>(rdB[j] + sb) : lds_read_tr_asm<48 * RB>(rdB[j] + sb);
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      // LDS returns in order: once at most (reads of the later k-steps) remain outstanding, this k-step's
+      // fragments have landed (the counter saturates at 15)
+      constexpr int PER = 2 * (MT + NT);
+      const int left = (KK - 1 - kk) * PER;
+      if (left >= 15) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+      else if (left == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 va[MT], vb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        short __attribute__((ext_vector_type(8))) vs = {fa[kk][i][0][0], fa[kk][i][0][1], fa[kk][i][0][2], fa[kk][i][0][3],
+                                                        fa[kk][i][1][0], fa[kk][i][1][1], fa[kk][i][1][2], fa[kk][i][1][3]};
+        va[i] = __builtin_bit_cast(bf16x8, vs);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        short __attribute__((ext_vector_type(8))) vs = {fb[kk][j][0][0], fb[kk][j][0][1], fb[kk][j][0][2], fb[kk][j][0][3],
+                                                        fb[kk][j][1][0], fb[kk][j][1][1], fb[kk][j][1][2], fb[kk][j][1][3]};
+        vb[j] = __builtin_bit_cast(bf16x8, vs);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(va[i], vb[j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // ---- epilogue: D[row = cout 4h + e][col = ci r16], fp32 atomics into the gradient
+  const int K = a.R * a.S * a.C;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h + e;
+      if (m >= a.Cout) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int c = c0 + wn * (BN / 2) + j * 16 + r16;
+        if (c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+      }
+    }
+  }
+#endif
+}
+
 int conv_check(const vlsfr_conv_desc* d, const char* who) {
   if (!d) return fail(VLSFR_EINVAL, "%s: null descriptor", who);
   if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0)
@@ -803,6 +1010,10 @@ void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad_glds")) {
+    g_wgrad_glds = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "wgrad_kt")) {
@@ -928,7 +1139,7 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   a.stride = d->stride;
   a.pad = d->pad;
   const int P = a.Nimg * a.Ho * a.Wo;
-  const int KT = g_wgrad_kt;
+  const int KT = g_wgrad_glds ? 64 : g_wgrad_kt;
   const int nkt = (P + KT - 1) / KT;
   const bool wide = d->Cin >= 128;
   const int BN = wide ? 128 : 64;
@@ -944,9 +1155,21 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   dim3 grid(a.n_coltiles * d->R * d->S, (d->Cout + BM - 1) / BM, splitk);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * d->R * d->S * d->Cin);
+  const bool glds = g_wgrad_glds && d->Cin % 8 == 0 && d->Cout % 8 == 0 && (size_t)P * d->Cout < (1ull << 30) &&
+                    (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30);
 #define VLSFR_WGRAD(BM_, BN_)                                                                           \
   do {                                                                                                 \
-    if (KT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 64>), grid, dim3(256), 0, st, a);      \
+    if (glds) {                                                                                        \
+      constexpr int lds_ = 2 * 64 * (BM_ + BN_) * 2;                                                   \
+      auto kern_ = conv_wgrad_glds_kernel<BM_, BN_, 64, 2>;                                            \
+      static bool attr_ = false;                                                                       \
+      if (!attr_) {                                                                                    \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
+        if (e_ != hipSuccess) return hip_fail(e_, "conv_wgrad_glds: hipFuncSetAttribute");             \
+        attr_ = true;                                                                                  \
+      }                                                                                                \
+      hipLaunchKernelGGL(kern_, grid, dim3(256), lds_, st, a);                                         \
+    } else if (KT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 64>), grid, dim3(256), 0, st, a); \
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 32>), grid, dim3(256), 0, st, a);               \
   } while (0)
   if (BM == 128 && BN == 128) VLSFR_WGRAD(128, 128);
