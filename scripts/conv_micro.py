@@ -14,9 +14,16 @@ x = torch.randn(B, hw, hw, cin, device="cuda").to(torch.bfloat16)
 w = (torch.randn(cout, 3, 3, cin, device="cuda") * 0.05).to(torch.bfloat16)
 d = ops.ConvDesc(B, hw, hw, cin, cout, 3, 3, 1, 1)
 stats = ops.new_sums(cout, "cuda") if os.environ.get("NOSTATS") is None else None
-for _ in range(3): ops.conv2d_fwd(x, w, d, stats=stats)
+mode = os.environ.get("MODE", "fwd")
+if mode == "wgrad":
+    dy = torch.randn(B, hw, hw, cout, device="cuda").to(torch.bfloat16)
+    dw = torch.zeros(cout, 3, 3, cin, device="cuda")
+    run = lambda: ops.conv2d_wgrad(dy, x, d, dw=dw)
+else:
+    run = lambda: ops.conv2d_fwd(x, w, d, stats=stats)
+for _ in range(3): run()
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(iters): ops.conv2d_fwd(x, w, d, stats=stats)
+for _ in range(iters): run()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / iters
 fl = 2.0 * B * hw * hw * cout * 9 * cin
 print("variant %d B=%d %dx%d@%d: %.1f us, %.1f TFLOP/s" % (variant, B, cin, cout, hw, dt * 1e6, fl / dt / 1e12))

@@ -39,6 +39,7 @@ bool g_prof_on = false;
 int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;
 int g_wgrad_target = 1024;
 int g_wgrad_kt = 32;
+int g_conv_dbg = 0;
 int g_wgrad_glds = 1;   // 1: LDS-DMA ring (conv_wgrad_glds_kernel), 0: register-staged kernel   // pixels per k-tile of the weight-gradient kernel (32 or 64)   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
@@ -583,6 +584,7 @@ struct WgradArgs {
   int R, S, stride, pad;
   int splitk;
   int n_coltiles;    // column tiles per tap = ceil(C / BN)
+  int dbg;           // diagnostics (vlsfr_set_option conv_dbg): 1 skips the epilogue atomics, 2 the k loop
 };
 
 template <int BM, int BN, int KT>
@@ -752,17 +754,18 @@ __device__ __forceinline__ short4v lds_read_tr_asm(uint32_t addr) {
 
 template <int ROWB>
 __device__ __forceinline__ int wg_swz(int row) {   // 32-byte block permutation of a ROWB-byte row
-  if constexpr (ROWB >= 256) return row & 7;
-  else return (row >> 1) & 3;
+  if constexpr (ROWB % 256 == 0) return row & 7;   // rows start on the same bank: 8 rows x 8 blocks
+  else return (row >> 1) & 3;                      // 128 (mod 256)-byte rows: row parity picks the bank half, 4 blocks each
 }
 
-template <int BM, int BN, int KT, int NST>
+// TPT > 1 (64-channel 3x3 layers): the column tile spans TPT = 3 taps of one filter row, 64 channels each
+// (a 64 x 64 tile per tap leaves the MFMAs waiting on LDS: 4 per 8 transposed reads).
+template <int BM, int BN, int KT, int NST, int TPT>
 __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int MT = BM / 32, NT = BN / 32;
   constexpr int RA = BM * 2, RB = BN * 2;            // row bytes
-  constexpr int RPIA = 1024 / RA, RPIB = 1024 / RB;  // pixel rows per 1-KiB DMA wave-instruction
-  constexpr int AI = KT / (4 * RPIA), BI = KT / (4 * RPIB);
+  constexpr int AI = KT * RA / 4096, BI = KT * RB / 4096;   // 1-KiB DMA wave-instructions per wave and stage
   constexpr int STAGE = KT * (RA + RB);
   constexpr int OOB = (int)0x80000000;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -773,8 +776,8 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int P = a.Nimg * a.Ho * a.Wo;
   const int m0 = blockIdx.y * BM;
-  const int tap = blockIdx.x / a.n_coltiles;
-  const int c0 = (blockIdx.x - tap * a.n_coltiles) * BN;
+  const int tap = TPT > 1 ? blockIdx.x * TPT : blockIdx.x / a.n_coltiles;          // first tap of the tile
+  const int c0 = TPT > 1 ? 0 : (blockIdx.x - tap * a.n_coltiles) * BN;
   const int tr = tap / a.S, ts = tap - tr * a.S;
   const int nkt = (P + KT - 1) / KT;
   const int per = (nkt + a.splitk - 1) / a.splitk;
@@ -791,25 +794,31 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   // ---- A (dy): lane -> (row in instruction, physical chunk); offset linear in the pixel index
   int a_off[AI];
   {
-    const int rin = lane / (RA / 16), pc = lane % (RA / 16);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const int row = (wave * AI + i) * RPIA + rin;
+      const int lin = (wave * AI + i) * 1024 + lane * 16;
+      const int row = lin / RA, pc = (lin % RA) / 16;
       const int lc = (((pc >> 1) ^ wg_swz<RA>(row)) << 1) | (pc & 1);
       a_off[i] = (m0 + lc * 8 < a.Cout) ? (row * a.Cout + m0 + lc * 8) * 2 : OOB;
     }
   }
   // ---- B (x, gathered at this workgroup's tap): per-instruction pixel coordinates
-  int b_n[BI], b_h[BI], b_w[BI], b_c[BI];
+  int b_n[BI], b_h[BI], b_w[BI], b_c[BI], b_s[BI];
   const int HoWo = a.Ho * a.Wo;
   const int dN = KT / HoWo, dRem = KT - dN * HoWo, dH = dRem / a.Wo, dW = dRem - dH * a.Wo;   // KT pixels as (images, rows, columns)
   {
-    const int rin = lane / (RB / 16), pc = lane % (RB / 16);
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const int row = (wave * BI + i) * RPIB + rin;
+      const int lin = (wave * BI + i) * 1024 + lane * 16;
+      const int row = lin / RB, pc = (lin % RB) / 16;
       const int lc = (((pc >> 1) ^ wg_swz<RB>(row)) << 1) | (pc & 1);
-      b_c[i] = (c0 + lc * 8 < a.C) ? (c0 + lc * 8) * 2 : OOB;
+      if (TPT > 1) {   // column = 64 * (tap in the row) + channel
+        b_s[i] = ts + ((lc * 8) >> 6);
+        b_c[i] = ((lc * 8) & 63) * 2;
+      } else {
+        b_s[i] = ts;
+        b_c[i] = (c0 + lc * 8 < a.C) ? (c0 + lc * 8) * 2 : OOB;
+      }
       const int64_t p = (int64_t)kt0 * KT + row;     // may be >= P: n >= Nimg marks it
       b_n[i] = (int)(p / HoWo);
       const int rem = (int)(p - (int64_t)b_n[i] * HoWo);
@@ -827,7 +836,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int hi = b_h[i] * a.stride - a.pad + tr;
-      const int wi = b_w[i] * a.stride - a.pad + ts;
+      const int wi = b_w[i] * a.stride - a.pad + b_s[i];
       const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && b_n[i] < a.Nimg;
       const int off = ((b_n[i] * a.H + hi) * a.W + wi) * a.C * 2 + b_c[i];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + KT * RA + (wave * BI + i) * 1024), 16,
@@ -865,6 +874,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   for (int s = 0; s < pre; ++s) issue(s);
 
   constexpr int KK = KT / 32;
+  if (!(a.dbg & 2))
   for (int it = 0; it < nk; ++it) {
     const int later = (nk - 1 - it) < (NST - 2) ? (nk - 1 - it) : (NST - 2);
     if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
@@ -919,6 +929,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+  if (a.dbg & 1) return;
   // ---- epilogue: D[row = cout 4h + e][col = ci r16], fp32 atomics into the gradient
   const int K = a.R * a.S * a.C;
 #pragma unroll
@@ -930,7 +941,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = c0 + wn * (BN / 2) + j * 16 + r16;
-        if (c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+        if (TPT > 1 || c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
       }
     }
   }
@@ -1010,6 +1021,10 @@ void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_dbg")) {
+    g_conv_dbg = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "wgrad_glds")) {
@@ -1142,17 +1157,21 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   const int KT = g_wgrad_glds ? 64 : g_wgrad_kt;
   const int nkt = (P + KT - 1) / KT;
   const bool wide = d->Cin >= 128;
-  const int BN = wide ? 128 : 64;
   const int BM = d->Cout >= 128 ? 128 : 64;
-  a.n_coltiles = (d->Cin + BN - 1) / BN;
-  const int tiles = a.n_coltiles * d->R * d->S * ((d->Cout + BM - 1) / BM);
+  // 64 -> 64 channel 3x3 layers: one column tile = the three taps of a filter row (LDS-DMA kernel only)
+  const bool row3 = g_wgrad_glds && d->Cin == 64 && BM == 64 && d->R == 3 && d->S == 3;
+  const int BN = row3 ? 192 : wide ? 128 : 64;
+  a.n_coltiles = row3 ? 1 : (d->Cin + BN - 1) / BN;
+  const int grid_x = row3 ? 3 : a.n_coltiles * d->R * d->S;
+  const int tiles = grid_x * ((d->Cout + BM - 1) / BM);
   if (splitk <= 0) {   // aim at g_wgrad_target workgroups (each adds its whole tile with fp32 atomics), >= 8 k-tiles each
     splitk = (g_wgrad_target + tiles - 1) / tiles;
     if (splitk > nkt / 8) splitk = nkt / 8;
     if (splitk < 1) splitk = 1;
   }
   a.splitk = splitk;
-  dim3 grid(a.n_coltiles * d->R * d->S, (d->Cout + BM - 1) / BM, splitk);
+  a.dbg = g_conv_dbg;
+  dim3 grid(grid_x, (d->Cout + BM - 1) / BM, splitk);
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * d->R * d->S * d->Cin);
   const bool glds = g_wgrad_glds && d->Cin % 8 == 0 && d->Cout % 8 == 0 && (size_t)P * d->Cout < (1ull << 30) &&
@@ -1161,7 +1180,7 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   do {                                                                                                 \
     if (glds) {                                                                                        \
       constexpr int lds_ = 2 * 64 * (BM_ + BN_) * 2;                                                   \
-      auto kern_ = conv_wgrad_glds_kernel<BM_, BN_, 64, 2>;                                            \
+      auto kern_ = conv_wgrad_glds_kernel<BM_, BN_, 64, 2, 1>;                                            \
       static bool attr_ = false;                                                                       \
       if (!attr_) {                                                                                    \
         hipError_t e_ = hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
@@ -1172,7 +1191,17 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
     } else if (KT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 64>), grid, dim3(256), 0, st, a); \
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 32>), grid, dim3(256), 0, st, a);               \
   } while (0)
-  if (BM == 128 && BN == 128) VLSFR_WGRAD(128, 128);
+  if (BN == 192) {
+    constexpr int lds_ = 2 * 64 * (64 + 192) * 2;
+    auto kern_ = conv_wgrad_glds_kernel<64, 192, 64, 2, 3>;
+    static bool attr_ = false;
+    if (!attr_) {
+      hipError_t e_ = hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
+      if (e_ != hipSuccess) return hip_fail(e_, "conv_wgrad_glds: hipFuncSetAttribute");
+      attr_ = true;
+    }
+    hipLaunchKernelGGL(kern_, grid, dim3(256), lds_, st, a);
+  } else if (BM == 128 && BN == 128) VLSFR_WGRAD(128, 128);
   else if (BM == 128) VLSFR_WGRAD(128, 64);
   else if (BN == 128) VLSFR_WGRAD(64, 128);
   else VLSFR_WGRAD(64, 64);
