@@ -41,6 +41,7 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 // the replicas).
 // ---------------------------------------------------------------------------------------------
 constexpr int REPL = VLSFR_BN_REPL;
+constexpr int UF = 4;   // independent rows (16-byte loads per tensor) in flight per thread in the streaming loops
 
 struct RowMap {
   int cg, col, rl, rpb;
@@ -106,14 +107,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, 
   const int64_t r0 = (int64_t)blockIdx.x * RB;
   const int64_t r1 = r0 + RB < M ? r0 + RB : M;
   if (m.active) {
-    for (int64_t r = r0 + m.rl; r < r1; r += m.rpb) {
-      bf8 xv;
-      xv.raw = *(const uint4*)(x + r * C + m.col * 8);
+    const int nrow = (int)(r1 - r0);
+    const u16* x0 = x + r0 * C + m.col * 8;
+    for (int rl = m.rl; rl < nrow; rl += UF * m.rpb) {
+      bf8 xv[UF];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float f = xv.get(j);
-        v[0][j] += f;
-        v[1][j] += f * f;
+      for (int u = 0; u < UF; ++u)
+        if (rl + u * m.rpb < nrow) xv[u].raw = *(const uint4*)(x0 + (rl + u * m.rpb) * C);
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        if (rl + u * m.rpb >= nrow) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float f = xv[u].get(j);
+          v[0][j] += f;
+          v[1][j] += f * f;
+        }
       }
     }
   }
@@ -143,7 +152,11 @@ struct BnApplyArgs {
   int out_nchw;           // 1: y index = n*(C*HW) + c*HW + hw (the flatten order of the reference's fc input)
 };
 
+// FLAGS (compile time, so that the streaming loop is one straight-line block): 1 PReLU, 2 residual,
+// 4 statistics of y, 8 flatten-order (NCHW) output
+template <int FLAGS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
+  constexpr bool PRELU = FLAGS & 1, RESID = FLAGS & 2, OSUMS = FLAGS & 4, NCHW = FLAGS & 8;
   extern __shared__ float sh[];   // scale[C], shift[C]; reused by the output-statistics reduction
   const int C = a.C;
   const int tid = threadIdx.x;
@@ -181,45 +194,48 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
     const int c = m.col * 8 + j;
     sc[j] = sh[c];
     sf[j] = sh[C + c];
-    sl[j] = a.slope ? a.slope[c] : 1.f;
+    sl[j] = PRELU ? a.slope[c] : 1.f;
     v[0][j] = v[1][j] = 0.f;
   }
   __syncthreads();   // sh is reused below
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
-  const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
+  const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
   if (m.active) {
-    // two independent rows per iteration: both rows' loads are issued before either is consumed
-    for (int64_t r = r0 + m.rl; r < r1; r += 2 * m.rpb) {
-      const int64_t rr[2] = {r, r + m.rpb};
-      const bool ok1 = rr[1] < r1;
-      bf8 xv[2], rs[2];
-      xv[0].raw = *(const uint4*)(a.x + rr[0] * C + m.col * 8);
-      if (ok1) xv[1].raw = *(const uint4*)(a.x + rr[1] * C + m.col * 8);
-      if (a.residual) {
-        rs[0].raw = *(const uint4*)(a.residual + rr[0] * C + m.col * 8);
-        if (ok1) rs[1].raw = *(const uint4*)(a.residual + rr[1] * C + m.col * 8);
-      }
+    // UF independent rows per iteration (all loads issued before any is consumed); 32-bit offsets from
+    // the block's first row
+    const u16* x0 = a.x + r0 * C + m.col * 8;
+    const u16* q0 = RESID ? a.residual + r0 * C + m.col * 8 : nullptr;
+    u16* y0 = a.y + r0 * C + m.col * 8;
+    for (int rl = m.rl; rl < nrow; rl += UF * m.rpb) {
+      bf8 xv[UF], rs[UF];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 1 && !ok1) break;
+      for (int u = 0; u < UF; ++u)
+        if (rl + u * m.rpb < nrow) {
+          xv[u].raw = *(const uint4*)(x0 + (rl + u * m.rpb) * C);
+          if (RESID) rs[u].raw = *(const uint4*)(q0 + (rl + u * m.rpb) * C);
+        }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        if (rl + u * m.rpb >= nrow) break;
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float z = xv[u].get(j) * sc[j] + sf[j];
-          if (a.slope) z = z > 0.f ? z : z * sl[j];
-          if (a.residual) z += rs[u].get(j);
+          if (PRELU) z = z > 0.f ? z : z * sl[j];
+          if (RESID) z += rs[u].get(j);
           o[j] = z;
         }
         const uint4 packed = pack8(o);
-        if (!a.out_nchw) {
-          *(uint4*)(a.y + rr[u] * C + m.col * 8) = packed;
+        if (!NCHW) {
+          *(uint4*)(y0 + (rl + u * m.rpb) * C) = packed;
         } else {
-          const int64_t n = rr[u] / a.HW;
-          const int hw = (int)(rr[u] - n * a.HW);
+          const int64_t row = r0 + rl + u * m.rpb;
+          const int64_t n = row / a.HW;
+          const int hw = (int)(row - n * a.HW);
 #pragma unroll
           for (int j = 0; j < 8; ++j) a.y[(n * C + m.col * 8 + j) * a.HW + hw] = f2bf(o[j]);
         }
-        if (a.out_sums) {
+        if (OSUMS) {
           bf8 yv;
           yv.raw = packed;   // statistics of what the next layer will actually read
 #pragma unroll
@@ -232,7 +248,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
       }
     }
   }
-  if (a.out_sums) block_reduce_to_replica<2>(v, m, C, sh, a.out_sums);
+  if (OSUMS) block_reduce_to_replica<2>(v, m, C, sh, a.out_sums);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -265,59 +281,71 @@ __device__ __forceinline__ float load_dy_nchw(const BnBwdArgs& a, int64_t r, int
   return bf2f(a.dy[(n * a.C + c) * a.HW + hw]);
 }
 
+// FLAGS: 1 PReLU, 2 dy in flatten (NCHW) order, 4 dx_add (apply kernel only)
+template <int FLAGS>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
+  constexpr bool PRELU = FLAGS & 1, NCHW = FLAGS & 2;
   extern __shared__ float sh[];
   const int C = a.C;
   const RowMap m = row_map(C);
-  float v[3][8], xs[8], xo[8], g[8], b[8], sl[8];   // xhat = x * xs + xo
+  // the loop accumulates sum dz, sum dz*x (RAW x) and sum dy*z over z <= 0; sum dz*xhat follows as
+  // invstd * (sum dz*x - mean * sum dz) -- fewer per-channel constants in registers.  z = x*zs + zo is only
+  // needed for the PReLU sign and slope gradient.
+  float v[3][8], zs[8], zo[8], sl[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
     v[0][j] = v[1][j] = v[2][j] = 0.f;
-    xs[j] = a.invstd[c];
-    xo[j] = -a.mean[c] * a.invstd[c];
-    g[j] = a.gamma ? a.gamma[c] : 1.f;
-    b[j] = a.beta ? a.beta[c] : 0.f;
-    sl[j] = a.slope ? a.slope[c] : 1.f;
+    const float is = a.invstd[c], g = a.gamma ? a.gamma[c] : 1.f;
+    zs[j] = is * g;
+    zo[j] = (a.beta ? a.beta[c] : 0.f) - a.mean[c] * is * g;
+    sl[j] = PRELU ? a.slope[c] : 1.f;
   }
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
-  const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
+  const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
   if (m.active) {
-    for (int64_t r = r0 + m.rl; r < r1; r += 2 * m.rpb) {
-      const int64_t rr[2] = {r, r + m.rpb};
-      const bool ok1 = rr[1] < r1;
-      bf8 xv[2], dv[2];
-      xv[0].raw = *(const uint4*)(a.x + rr[0] * C + m.col * 8);
-      if (ok1) xv[1].raw = *(const uint4*)(a.x + rr[1] * C + m.col * 8);
-      if (!a.dy_nchw) {
-        dv[0].raw = *(const uint4*)(a.dy + rr[0] * C + m.col * 8);
-        if (ok1) dv[1].raw = *(const uint4*)(a.dy + rr[1] * C + m.col * 8);
-      }
+    const u16* x0 = a.x + r0 * C + m.col * 8;
+    const u16* d0 = a.dy + r0 * C + m.col * 8;
+    for (int rl = m.rl; rl < nrow; rl += UF * m.rpb) {
+      bf8 xv[UF], dv[UF];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u == 1 && !ok1) break;
+      for (int u = 0; u < UF; ++u)
+        if (rl + u * m.rpb < nrow) {
+          xv[u].raw = *(const uint4*)(x0 + (rl + u * m.rpb) * C);
+          if (!NCHW) dv[u].raw = *(const uint4*)(d0 + (rl + u * m.rpb) * C);
+        }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        if (rl + u * m.rpb >= nrow) break;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xhat = xv[u].get(j) * xs[j] + xo[j];
-          const float dyv = a.dy_nchw ? load_dy_nchw(a, rr[u], m.col * 8 + j) : dv[u].get(j);
+          const float xf = xv[u].get(j);
+          const float dyv = NCHW ? load_dy_nchw(a, r0 + rl + u * m.rpb, m.col * 8 + j) : dv[u].get(j);
           float dz = dyv;
-          if (a.slope) {
-            const float z = xhat * g[j] + b[j];
-            if (z <= 0.f) {
-              v[2][j] += dyv * z;
-              dz = dyv * sl[j];
-            }
+          if (PRELU) {
+            const float z = xf * zs[j] + zo[j];
+            const bool neg = z <= 0.f;
+            v[2][j] += neg ? dyv * z : 0.f;
+            dz = neg ? dyv * sl[j] : dyv;
           }
           v[0][j] += dz;
-          v[1][j] += dz * xhat;
+          v[1][j] += dz * xf;
         }
       }
     }
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {   // sum dz*xhat from the raw-x sum (linear, so it commutes with the reduction)
+    const int c = m.col * 8 + j;
+    const float is = a.invstd[c];
+    v[1][j] = is * (v[1][j] - a.mean[c] * v[0][j]);
+  }
   block_reduce_to_replica<3>(v, m, C, sh, a.red);
 }
 
+template <int FLAGS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
+  constexpr bool PRELU = FLAGS & 1, NCHW = FLAGS & 2, DXADD = FLAGS & 4;
   extern __shared__ float sh[];   // k0[C] = gamma*invstd, k1[C] = mean dz, k2[C] = mean dz*xhat
   const int C = a.C;
   const int tid = threadIdx.x;
@@ -344,52 +372,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   __syncthreads();
   const RowMap m = row_map(C);
   if (!m.active) return;
-  float k0[8], k1[8], k2[8], xs[8], xo[8], g[8], b[8], sl[8];
+  // dx = k0*(dz - k1 - xhat*k2) = A*dz + Bx*x + Cc with xhat = x*invstd - mean*invstd folded in;
+  // dz = dy * (z <= 0 ? slope : 1): As = A*slope
+  float A[8], As[8], Bx[8], Cc[8], zs[8], zo[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
-    k0[j] = sh[c];
-    k1[j] = sh[C + c];
-    k2[j] = sh[2 * C + c];
-    xs[j] = a.invstd[c];
-    xo[j] = -a.mean[c] * a.invstd[c];
-    g[j] = a.gamma ? a.gamma[c] : 1.f;
-    b[j] = a.beta ? a.beta[c] : 0.f;
-    sl[j] = a.slope ? a.slope[c] : 1.f;
+    const float k0 = sh[c], k1 = sh[C + c], k2 = sh[2 * C + c];
+    const float is = a.invstd[c], xo = -a.mean[c] * is, g = a.gamma ? a.gamma[c] : 1.f;
+    A[j] = k0;
+    As[j] = k0 * (PRELU ? a.slope[c] : 1.f);
+    Bx[j] = -k0 * k2 * is;
+    Cc[j] = -k0 * (k1 + k2 * xo);
+    zs[j] = is * g;
+    zo[j] = (a.beta ? a.beta[c] : 0.f) + xo * g;
   }
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
-  const int64_t r1 = r0 + a.RB < a.M ? r0 + a.RB : a.M;
-  for (int64_t r = r0 + m.rl; r < r1; r += 2 * m.rpb) {
-    const int64_t rr[2] = {r, r + m.rpb};
-    const bool ok1 = rr[1] < r1;
-    bf8 xv[2], dv[2], av[2];
-    xv[0].raw = *(const uint4*)(a.x + rr[0] * C + m.col * 8);
-    if (ok1) xv[1].raw = *(const uint4*)(a.x + rr[1] * C + m.col * 8);
-    if (!a.dy_nchw) {
-      dv[0].raw = *(const uint4*)(a.dy + rr[0] * C + m.col * 8);
-      if (ok1) dv[1].raw = *(const uint4*)(a.dy + rr[1] * C + m.col * 8);
-    }
-    if (a.dx_add) {
-      av[0].raw = *(const uint4*)(a.dx_add + rr[0] * C + m.col * 8);
-      if (ok1) av[1].raw = *(const uint4*)(a.dx_add + rr[1] * C + m.col * 8);
-    }
+  const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
+  const u16* x0 = a.x + r0 * C + m.col * 8;
+  const u16* d0 = a.dy + r0 * C + m.col * 8;
+  const u16* q0 = DXADD ? a.dx_add + r0 * C + m.col * 8 : nullptr;
+  u16* o0 = a.dx + r0 * C + m.col * 8;
+  for (int rl = m.rl; rl < nrow; rl += UF * m.rpb) {
+    bf8 xv[UF], dv[UF], av[UF];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u == 1 && !ok1) break;
+    for (int u = 0; u < UF; ++u)
+      if (rl + u * m.rpb < nrow) {
+        xv[u].raw = *(const uint4*)(x0 + (rl + u * m.rpb) * C);
+        if (!NCHW) dv[u].raw = *(const uint4*)(d0 + (rl + u * m.rpb) * C);
+        if (DXADD) av[u].raw = *(const uint4*)(q0 + (rl + u * m.rpb) * C);
+      }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      if (rl + u * m.rpb >= nrow) break;
       float o[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float xhat = xv[u].get(j) * xs[j] + xo[j];
-        float dz = a.dy_nchw ? load_dy_nchw(a, rr[u], m.col * 8 + j) : dv[u].get(j);
-        if (a.slope) {
-          const float z = xhat * g[j] + b[j];
-          if (z <= 0.f) dz *= sl[j];
-        }
-        float d = k0[j] * (dz - k1[j] - xhat * k2[j]);
-        if (a.dx_add) d += av[u].get(j);
+        const float xf = xv[u].get(j);
+        const float dyv = NCHW ? load_dy_nchw(a, r0 + rl + u * m.rpb, m.col * 8 + j) : dv[u].get(j);
+        float ad = A[j];
+        if (PRELU) ad = (xf * zs[j] + zo[j] <= 0.f) ? As[j] : A[j];
+        float d = ad * dyv + (Bx[j] * xf + Cc[j]);
+        if (DXADD) d += av[u].get(j);
         o[j] = d;
       }
-      *(uint4*)(a.dx + rr[u] * C + m.col * 8) = pack8(o);
+      *(uint4*)(o0 + (rl + u * m.rpb) * C) = pack8(o);
     }
   }
 }
@@ -631,7 +658,16 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
   bn_geom(M, C, &RB, &nblk);
   BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, sums, gamma, beta, slope, (const u16*)residual, save_mean,
                 save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw};
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, a);
+  const int flags = (slope ? 1 : 0) | (residual ? 2 : 0) | (out_sums ? 4 : 0) | (out_nchw ? 8 : 0);
+  const dim3 grid(nblk), block(256);
+  const size_t shb = 2 * C * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define VLSFR_CASE(F) case F: hipLaunchKernelGGL(bn_apply_kernel<F>, grid, block, shb, st, a); break;
+  switch (flags) {
+    VLSFR_CASE(0) VLSFR_CASE(1) VLSFR_CASE(2) VLSFR_CASE(3) VLSFR_CASE(4) VLSFR_CASE(5) VLSFR_CASE(6) VLSFR_CASE(7)
+    VLSFR_CASE(8) VLSFR_CASE(9) VLSFR_CASE(10) VLSFR_CASE(11) VLSFR_CASE(12) VLSFR_CASE(13) VLSFR_CASE(14) VLSFR_CASE(15)
+  }
+#undef VLSFR_CASE
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_apply");
   return VLSFR_OK;
 }
@@ -646,9 +682,22 @@ int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_
   bn_geom(M, C, &RB, &nblk);
   BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
               (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw};
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 3 * C * sizeof(float), st, a);
+  const int rflags = (slope ? 1 : 0) | (dy_nchw ? 2 : 0);
+  const int aflags = rflags | (dx_add ? 4 : 0);
+  const dim3 grid(nblk), block(256);
+  const size_t shb = 3 * C * sizeof(float);
+  switch (rflags) {
+    case 0: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, shb, st, a); break;
+    case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, shb, st, a); break;
+    case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, block, shb, st, a); break;
+    default: hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, grid, block, shb, st, a); break;
+  }
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward reduce");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk), dim3(256), 3 * C * sizeof(float), st, a);
+#define VLSFR_CASE(F) case F: hipLaunchKernelGGL(bn_bwd_apply_kernel<F>, grid, block, shb, st, a); break;
+  switch (aflags) {
+    VLSFR_CASE(0) VLSFR_CASE(1) VLSFR_CASE(2) VLSFR_CASE(3) VLSFR_CASE(4) VLSFR_CASE(5) VLSFR_CASE(6) VLSFR_CASE(7)
+  }
+#undef VLSFR_CASE
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward apply");
   return VLSFR_OK;
 }
