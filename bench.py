@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--feat", type=int, default=512)
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning switch (vlsfr_set_option), repeatable")
     ap.add_argument("--conv-glds", type=int, default=-1, help="A/B switch for the conv kernel variant (vlsfr_set_option)")
     ap.add_argument("--pool", default="sharded", choices=["sharded", "replicated"],
@@ -145,6 +146,9 @@ def main():
     Q = args.queue or args.identities
     torch.manual_seed(1234)                                   # identical initial weights on every rank
     model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99).cuda()
+    if args.serial:
+        model.__dict__['concurrent_streams'] = False
+        model.probe_net.concurrent_backward = False
     n_res = min(Q, args.identities)
     model.lru.restore(list(zip(range(n_res), range(n_res))))  # steady state: the pool is full (lru.py:113)
     cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
@@ -187,9 +191,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_ms = []
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    evs[0].record()
     for i in range(args.steps):
         th = time.perf_counter()
         loss = one_step(args.warmup + i)
+        evs[i + 1].record()
         host_ms.append((time.perf_counter() - th) * 1e3)
     torch.cuda.synchronize()
     if dist is not None:
@@ -197,8 +204,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     L.vlsfr_profile_enable(0)
-    note("timed region done: %.3f s for %d steps; host-side issue time per step (ms): %s" %
-         (dt, args.steps, " ".join("%.1f" % v for v in host_ms)))
+    note("timed region done: %.3f s for %d steps; GPU ms per step: %s; host-side issue ms per step: %s" %
+         (dt, args.steps, " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)),
+          " ".join("%.1f" % v for v in host_ms)))
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

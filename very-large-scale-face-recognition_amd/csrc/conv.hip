@@ -40,6 +40,7 @@ int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;
 int g_wgrad_target = 1024;
 int g_wgrad_kt = 32;
 int g_conv_dbg = 0;
+long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
 int g_wgrad_glds = 1;   // 1: LDS-DMA ring (conv_wgrad_glds_kernel), 0: register-staged kernel   // pixels per k-tile of the weight-gradient kernel (32 or 64)   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
@@ -76,6 +77,7 @@ struct ConvArgs {
   int splitk;
   int out_f32;
   float* stats;      // optional [VLSFR_BN_REPL][2][Mrows] BatchNorm statistics of the rounded output
+  long long* trace;  // diagnostics: per-phase clock stamps of waves 0 and 4 of one workgroup (vlsfr_conv_trace), or nullptr
 };
 
 // LDS image of a k-tile: [rows][BK] bf16, the 16-byte chunks of a row XOR-swizzled with the row so
@@ -306,8 +308,8 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
   ((f[I] = lds_read128_asm<BASE + I * STRIDE>(addr)), ...);
 }
 
-template <int BM, int BN, int BK, int NST, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a) {
+template <int BM, int BN, int BK, int NST, int NW, bool PP = false>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN >= 256 * 128) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only
   // wave grid WM x WN (NW waves): each wave keeps (BM / WM) x (BN / WN) of the tile; the 8-wave
   // 256 x 128 / 128 x 256 tiles raise the FLOPs per byte a CU has to pull from L2 by a third over
@@ -452,6 +454,87 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_igemm_glds_kernel(ConvArgs a)
   const int pre = nk < NST - 1 ? nk : NST - 1;
   for (int s = 0; s < pre; ++s) issue(s);
 
+  if constexpr (PP) {
+    // ---- ping-pong schedule (8 waves = two groups of one wave per SIMD, three 64-deep stages, one
+    // workgroup per CU).  Phases alternate: while one group runs the 32 MFMAs of a k-tile from
+    // registers, the other reads its fragments of the next tile from LDS and issues its slice of the
+    // DMAs two tiles ahead; one workgroup barrier ends every phase.  Group 0 reads tile t in phase 2t
+    // and multiplies in 2t + 1, group 1 one phase later.  Tile t + 2 goes into the stage of tile
+    // t - 1, whose last readers (group 1, phase 2t - 1) are behind the barrier; a wave's slice of tile
+    // t + 1 has landed (counted vmcnt) before the barrier that opens phase 2t + 2.
+    static_assert(NW == 8 && BK == 64 && NST == 3, "ping-pong variant: 8 waves, 64-deep tiles, 3 stages");
+    constexpr int NDMA = AI + BI;
+    const int grp = wave >> 2;
+    bf16x8 fa[2][MT], fb[2][NT];
+    auto read_frags = [&](int t) {
+      const uint32_t sbase = lds0 + (uint32_t)((t % NST) * STAGE);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint32_t rd = sbase + (uint32_t)(r16 * RSB + (((kk * 4 + h) ^ swz<BK>(r16)) << 4));
+        lds_read_frags<16 * RSB, 0>(fa[kk], rd + (uint32_t)(wm * (BM / WM) * RSB), std::make_integer_sequence<int, MT>{});
+        lds_read_frags<16 * RSB, BM * RSB>(fb[kk], rd + (uint32_t)(wn * (BN / WN) * RSB),
+                                           std::make_integer_sequence<int, NT>{});
+      }
+    };
+    auto multiply = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[kk][i], fb[kk][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // tile 0 complete (the slice of tile 1 may still be in flight)
+    if (pre >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool tr_on = a.trace && blockIdx.x == 7 && blockIdx.y == 0 && (wave & 3) == 0;
+    long long* tr = a.trace + (wave >> 2) * 64 * 8;
+#define VLSFR_STAMP(t, k)                                                     \
+  if (tr_on && (t) < 64) {                                                    \
+    const long long c_ = (long long)__builtin_readcyclecounter();             \
+    if (lane == 0) __builtin_nontemporal_store(c_, tr + (t) * 8 + (k));       \
+  }
+    if (grp == 0) {
+      for (int t = 0; t < nk; ++t) {
+        VLSFR_STAMP(t, 0)
+        read_frags(t);                                     // phase 2t
+        if (t + 2 < nk) issue((t + 2) % NST);
+        VLSFR_STAMP(t, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        VLSFR_STAMP(t, 2)
+        __builtin_amdgcn_s_barrier();
+        VLSFR_STAMP(t, 3)
+        multiply();                                        // phase 2t + 1
+        VLSFR_STAMP(t, 4)
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VLSFR_STAMP(t, 5)
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      __builtin_amdgcn_s_barrier();                        // phase 0: group 0 reads tile 0
+      for (int t = 0; t < nk; ++t) {
+        VLSFR_STAMP(t, 0)
+        read_frags(t);                                     // phase 2t + 1
+        if (t + 2 < nk) issue((t + 2) % NST);
+        VLSFR_STAMP(t, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        VLSFR_STAMP(t, 2)
+        if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        VLSFR_STAMP(t, 3)
+        __builtin_amdgcn_s_barrier();
+        VLSFR_STAMP(t, 4)
+        multiply();                                        // phase 2t + 2
+        VLSFR_STAMP(t, 5)
+        if (t + 1 < nk) __builtin_amdgcn_s_barrier();
+      }
+    }
+#undef VLSFR_STAMP
+  } else
   for (int it = 0; it < nk; ++it) {
     // tiles issued after tile `it` may stay in flight: min(NST - 2, nk - 1 - it) of them, (AI + BI) DMAs each
     const int later = (nk - 1 - it) < (NST - 2) ? (nk - 1 - it) : (NST - 2);
@@ -962,11 +1045,11 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
 
 inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-template <int BM, int BN, int BK, int NST, int NW = 4>
+template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false>
 int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr_set = false;
-  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW>;
+  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW, PP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "conv_igemm_glds: hipFuncSetAttribute");
@@ -986,6 +1069,7 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
 
 int run_igemm(ConvArgs a, hipStream_t st) {
   const int P = a.Nimg * a.Ho * a.Wo;
+  a.trace = g_conv_trace;
   ProfScope prof(st, 0, 2.0 * P * (double)a.Mrows * a.R * a.S * a.C);
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
@@ -999,6 +1083,22 @@ int run_igemm(ConvArgs a, hipStream_t st) {
     else if (g_use_glds == 5)   // 8-wave tiles, 3-stage ring, one workgroup per CU
       rc = a.Mrows >= 256 ? launch_igemm_glds<256, 128, 64, 3, 8>(a, P, st)
            : big          ? launch_igemm_glds<128, 256, 64, 3, 8>(a, P, st)
+                          : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 8)   // 256 x 128 tile, 4 waves of 128 x 64, three 32-deep stages, two workgroups per CU
+      rc = a.Mrows >= 256 ? launch_igemm_glds<256, 128, 32, 3, 4>(a, P, st)
+           : big          ? launch_igemm_glds<128, 128, 64, 2>(a, P, st)
+                          : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 9)   // ping-pong 8-wave tiles where the channel count allows
+      rc = a.Mrows >= 256 ? launch_igemm_glds<256, 128, 64, 3, 8, true>(a, P, st)
+           : big          ? launch_igemm_glds<128, 256, 64, 3, 8, true>(a, P, st)
+                          : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 10)   // largest tiles the channel count allows, standard 2-stage loop, 8 waves, one workgroup per CU
+      rc = a.Mrows >= 256 ? launch_igemm_glds<256, 256, 64, 2, 8>(a, P, st)
+           : big          ? launch_igemm_glds<128, 256, 64, 2, 8>(a, P, st)
+                          : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 11)
+      rc = a.Mrows >= 256 ? launch_igemm_glds<256, 128, 64, 2, 8>(a, P, st)
+           : big          ? launch_igemm_glds<128, 256, 64, 2, 8>(a, P, st)
                           : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
@@ -1045,6 +1145,11 @@ int vlsfr_set_option(const char* name, int32_t value) {
     return VLSFR_OK;
   }
   return fail(VLSFR_EINVAL, "vlsfr_set_option: unknown option");
+}
+
+int vlsfr_conv_trace(void* device_buffer) {   // diagnostics, see ConvArgs::trace
+  g_conv_trace = (long long*)device_buffer;
+  return VLSFR_OK;
 }
 
 int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops, int64_t* launches) {

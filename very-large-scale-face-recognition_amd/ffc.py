@@ -84,6 +84,12 @@ class FFC(Module):
         fills 1.5 waves of workgroups) is covered by the kernels of the other.  The EMA of the rollback pass
         reads only probe PARAMETERS, which the probe forward does not change, so doing it first is the
         reference order's result."""
+        if not self.__dict__.get('concurrent_streams', True):        # A/B switch (bench.py --serial)
+            with torch.no_grad():
+                if update_gallery:
+                    self._momentum_update_gallery()
+                g = self.gallery_net(g_data)
+            return self.probe_net(p_data), g
         main = torch.cuda.current_stream()
         side = self.__dict__.get('_side_stream')
         if side is None or side.device != main.device:
