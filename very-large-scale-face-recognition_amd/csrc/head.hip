@@ -914,7 +914,10 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   pl->n_rowblk = (c->B + ROWS_WG - 1) / ROWS_WG;
   pl->Bp = pl->n_rowblk * ROWS_WG;
   int64_t tiles = (c->Q + TQ - 1) / TQ;
-  int nch = c->n_chunks > 0 ? c->n_chunks : 256;
+  // default: ~512 workgroups in the sweep (measured at B = 64 and 256: fewer, larger chunks shrink the
+  // partial-state traffic of the finish kernel; below 256 workgroups the sweep loses balance)
+  int nch = c->n_chunks > 0 ? c->n_chunks : 512 / pl->n_rowblk;
+  if (c->n_chunks <= 0) nch = nch > 256 ? 256 : (nch < 32 ? 32 : nch);
   if (nch > tiles) nch = (int)tiles;
   int64_t per = (tiles + nch - 1) / nch;
   if (per > 1024) {   // bound the special-column bitmap (4 KiB of LDS)

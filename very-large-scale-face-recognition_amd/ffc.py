@@ -117,9 +117,35 @@ class FFC(Module):
         return head.run_pass(p, g, probe_label, gallery_label, transactional=True)
 
     def forward(self, x, y, x_label, y_label):                        # ffc.py:264-267
-        loss2 = self.forward_impl_rollback(x, y, x_label, y_label)
-        loss1 = self.forward_impl(y, x, y_label, x_label)
-        return loss1 + loss2
+        if not self.__dict__.get('concurrent_streams', True) or not x.is_cuda:
+            loss2 = self.forward_impl_rollback(x, y, x_label, y_label)
+            loss1 = self.forward_impl(y, x, y_label, x_label)
+            return loss1 + loss2
+        # Same two passes, with the head of the rollback pass on a third stream beside the backbones of the
+        # commit pass (the head needs only p, g of ITS pass; pool and LRU state are touched in program order:
+        # both heads run on the head stream, the host bookkeeping is synchronous).
+        head = self._ensure_head()
+        main = torch.cuda.current_stream()
+        hs = self.__dict__.get('_head_stream')
+        if hs is None or hs.device != main.device:
+            hs = torch.cuda.Stream(device=main.device)
+            self.__dict__['_head_stream'] = hs
+        p1, g1 = self.embed_pair(x, y, update_gallery=True)
+        hs.wait_stream(main)
+        with torch.cuda.stream(hs):
+            loss2 = head.run_pass(p1, g1, x_label, y_label, transactional=True)
+        p1.record_stream(hs)
+        g1.record_stream(hs)
+        p2, g2 = self.embed_pair(y, x, update_gallery=False)
+        hs.wait_stream(main)
+        with torch.cuda.stream(hs):
+            loss1 = head.run_pass(p2, g2, y_label, x_label, transactional=False)
+            total = loss1 + loss2
+        p2.record_stream(hs)
+        g2.record_stream(hs)
+        main.wait_stream(hs)
+        total.record_stream(main)
+        return total
 
 
 class DcpHeadState(object):

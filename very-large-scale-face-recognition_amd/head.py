@@ -7,6 +7,7 @@ autograd node whose backward is the dL/dp the kernel already produced (the pool 
 nothing else needs a gradient).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -83,7 +84,7 @@ class DcpHead(object):
         self.queue = queue                       # [2, Q, D] fp32, device, contiguous (shared with FFC.queue)
         self.Q, self.D = int(queue.shape[1]), int(queue.shape[2])
         self.scale, self.margin, self.loss_type = float(scale), float(margin), loss_type
-        self.precise, self.n_chunks = bool(precise), int(n_chunks)
+        self.precise, self.n_chunks = bool(precise), int(n_chunks or os.environ.get('VLSFR_HEAD_CHUNKS', 0))
         self.hard_neg = min(max(int(self.Q * 0.0002), 3), 10)          # ffc.py:48
         self.lru = LRU(self.Q)                                        # ffc.py:40
         self.qp = np.zeros(self.Q, dtype=np.uint8)                    # ffc.py:41-43
