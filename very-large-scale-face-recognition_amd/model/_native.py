@@ -3,6 +3,7 @@ a backbone are parameter containers only; forward / backward are single calls in
 (csrc/iresnet.cpp, csrc/mobilenet.cpp), which accumulates gradients straight into the parameters'
 .grad buffers."""
 import ctypes
+import weakref
 
 import torch
 from torch import nn
@@ -29,10 +30,10 @@ class _BackboneFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, *params):
-        emb, ws = net._run_forward(x, save=True)
-        ctx.net, ctx.ws, ctx.B = net, ws, x.shape[0]
         ctx.slot = net._fwd_slot
         net._fwd_slot ^= 1
+        emb, ws = net._run_forward(x, save=True, owner=ctx, slot=ctx.slot)
+        ctx.net, ctx.ws, ctx.B = net, ws, x.shape[0]
         return emb
 
     @staticmethod
@@ -74,6 +75,8 @@ class NativeBackbone(nn.Module):
         self._w_sig = None
         self._scratch = None
         self._scratch_alt = None
+        self._ctx_pool = [None, None]      # saved-activation buffers of the two passes of a step, reused across steps
+        self._ctx_owner = [None, None]     # weakref to the autograd ctx that still needs the buffer
         self._eval_ctx = None
         self._fwd_slot = 0
         self._join_queued = False
@@ -160,7 +163,23 @@ class NativeBackbone(nn.Module):
         if self._scratch is None or self._scratch.numel() < sizes[2] or self._scratch.device != device:
             self._scratch = torch.empty(sizes[2], dtype=torch.uint8, device=device)
 
-    def _run_forward(self, x, save):
+    def _ctx_buffer(self, nbytes, device, owner, slot):
+        """Saved-activation buffer for one training forward: the two passes of a step alternate between two
+        persistent buffers (multi-GB allocations per step would go through the caching allocator, whose
+        occasional hipMalloc / hipFree under stream-recorded blocks stalls the queue); a buffer whose
+        previous owner has not run backward yet is not reused -- that pass gets a fresh allocation."""
+        prev = self._ctx_owner[slot]() if self._ctx_owner[slot] is not None else None
+        free = prev is None or getattr(prev, "ws", None) is None
+        buf = self._ctx_pool[slot]
+        if not free:
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ctx_pool[slot] = buf
+        self._ctx_owner[slot] = weakref.ref(owner) if owner is not None else None
+        return buf
+
+    def _run_forward(self, x, save, owner=None, slot=0):
         if not x.is_cuda:
             raise _lib.VlsfrError("%s.forward needs a device tensor: the backbone has no CPU path" % type(self).__name__)
         L = _lib.lib()
@@ -171,7 +190,7 @@ class NativeBackbone(nn.Module):
         params, running = self._tables()
         self._prepare(h, sizes, params, x.device)
         if save:
-            ws = torch.empty(sizes[1], dtype=torch.uint8, device=x.device)
+            ws = self._ctx_buffer(sizes[1], x.device, owner, slot)
         else:
             if self._eval_ctx is None or self._eval_ctx.numel() < sizes[1] or self._eval_ctx.device != x.device:
                 self._eval_ctx = torch.empty(sizes[1], dtype=torch.uint8, device=x.device)
