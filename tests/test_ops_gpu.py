@@ -37,15 +37,25 @@ IR_SHAPES = [
 ]
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["regstage", "glds64x4", "glds32x4", "glds64x2", "glds32x5", "glds8w"])
+CONV_VARIANTS = [("conv_glds", 0, "regstage"), ("conv_glds", 1, "glds64x4"), ("conv_glds", 2, "glds32x4"),
+                 ("conv_glds", 3, "glds64x2"), ("conv_glds", 4, "glds32x5"), ("conv_glds", 5, "glds8w"),
+                 ("conv_glds", 9, "pingpong"), ("conv_glds", 10, "tile256"), ("conv_halo", 2, "halo"),
+                 ("wgrad_glds", 0, "wgrad_regstage")]
+CONV_DEFAULTS = {"conv_glds": -1, "conv_halo": 0, "wgrad_glds": 1}
+
+
+@pytest.fixture(params=CONV_VARIANTS, ids=[v[2] for v in CONV_VARIANTS])
 def conv_variant(request):
-    """Every implicit-GEMM kernel variant (register-staged, and the LDS-DMA rings) must agree."""
+    """Every convolution kernel variant behind vlsfr_set_option (register-staged, the LDS-DMA rings, the
+    ping-pong and 256-wide tiles, the halo-patch kernel, the register-staged weight gradient) must agree
+    with the default one and with the fp32 reference."""
     import ctypes
     from vlsfr_amd import _lib
     L = _lib.lib()
-    L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(request.param))
+    name, value, _ = request.param
+    L.vlsfr_set_option(name.encode(), ctypes.c_int32(value))
     yield request.param
-    L.vlsfr_set_option(b"conv_glds", ctypes.c_int32(-1))
+    L.vlsfr_set_option(name.encode(), ctypes.c_int32(CONV_DEFAULTS[name]))
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,hw", IR_SHAPES)

@@ -35,13 +35,17 @@ struct ProfRec {
   int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad
 };
 bool g_prof_on = false;
+// vlsfr_set_option switches (A/B and diagnostics; the defaults are what the measurements in DESIGN.md section 8 chose)
 #define VLSFR_DEFAULT_CONV_VARIANT 3
-int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;
-int g_wgrad_target = 1024;
-int g_wgrad_kt = 32;
-int g_conv_dbg = 0;
+int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // "conv_glds": 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4,
+                                               // 3 = BK64 x 2 (default), 4 = BK32 x 5, 5 = 8-wave tiles, 6 / 7 = BK32 x 3 / x 2, 8 = 256x128 4-wave,
+                                               // 9 = ping-pong 8-wave tiles, 10 / 11 = 256x256 / 256x128 8-wave tiles in the standard loop
+int g_use_halo = 0;          // "conv_halo": halo-patch kernel for 3x3 / stride-1 layers: 0 never (no end-to-end gain measured), 1 the 64-channel layers, 2 all
+int g_wgrad_glds = 1;        // "wgrad_glds": 1 LDS-DMA ring (conv_wgrad_glds_kernel), 0 register-staged kernel
+int g_wgrad_kt = 32;         // "wgrad_kt": pixels per k-tile of the register-staged weight-gradient kernel (32 or 64)
+int g_wgrad_target = 1024;   // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into
+int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
-int g_wgrad_glds = 1;   // 1: LDS-DMA ring (conv_wgrad_glds_kernel), 0: register-staged kernel   // pixels per k-tile of the weight-gradient kernel (32 or 64)   // vlsfr_set_option("conv_glds", v): 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4, 3 = BK64 x 2
 std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -308,6 +312,98 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
   ((f[I] = lds_read128_asm<BASE + I * STRIDE>(addr)), ...);
 }
 
+// Shared epilogue of the LDS-DMA convolution kernels: lane (r16, h) of wave (wm, wn) holds channels
+// m0 + wm*(BM/WM) + 16 i + 4h + e of pixels p0 + wn*(BN/WN) + 16 j + r16.  fp32 output (plain or split-K
+// atomics) or bf16 output with the fused BatchNorm statistics; red_lds = BM*WN*2 floats of LDS nobody reads.
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
+                                              int r16, int h, int tid, float* red_lds) {
+  // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
+  const int mw = m0 + wm * (BM / WM) + 4 * h;     // + 16 i
+  const int pw = p0 + wn * (BN / WN) + r16;       // + 16 j
+  if (a.out_f32) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int p = pw + j * 16;
+      if (p >= P) continue;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = mw + i * 16;
+        if (m >= a.Mrows) continue;
+        float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
+        if (a.splitk > 1) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
+        } else {
+          *(f32x4*)dst = acc[i][j];
+        }
+      }
+    }
+    return;
+  }
+  // bf16 output; the BatchNorm statistics are taken from the ROUNDED values (what the consumer reads)
+  float cs[MT][4], cq[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
+  u16* yrow = (u16*)a.y + (size_t)pw * a.Mrows + mw;
+  auto store = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const bool okp = FULL || pw + j * 16 < P;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bool ok = okp && (FULL || mw + i * 16 < a.Mrows);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (__bf16)acc[i][j][e];
+          const float f = ok ? (float)o[e] : 0.f;
+          cs[i][e] += f;
+          cq[i][e] += f * f;
+        }
+        if (ok) *(bf16x4*)(yrow + (size_t)j * 16 * a.Mrows + i * 16) = o;
+      }
+    }
+  };
+  if (p0 + BN <= P && m0 + BM <= a.Mrows) store(std::true_type{});
+  else store(std::false_type{});
+  if (a.stats) {
+    // fused BatchNorm statistics: the 16 pixel lanes of a row are summed with DPP adds (no LDS
+    // round trips), lane r16 of row h keeps channel 16 (r16 >> 2) + 4h + (r16 & 3); the WN pixel
+    // halves of the workgroup meet in the LDS stage the last k-tile did not use (its readers all
+    // passed the last barrier), then ONE global atomic per channel and workgroup.
+    float sv = 0.f, qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float s = row16_sum(cs[i][e]), q = row16_sum(cq[i][e]);
+        if (r16 == i * 4 + e) {
+          sv = s;
+          qv = q;
+        }
+      }
+    float* red = red_lds;   // [WN][2][BM]
+    if (r16 < MT * 4) {
+      const int ml = wm * (BM / WM) + (r16 >> 2) * 16 + 4 * h + (r16 & 3);
+      red[(wn * 2 + 0) * BM + ml] = sv;
+      red[(wn * 2 + 1) * BM + ml] = qv;
+    }
+    __syncthreads();
+    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
+    for (int i = tid; i < 2 * BM; i += NW * 64) {
+      const int k = i / BM, ml = i - k * BM;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) v += red[(w * 2 + k) * BM + ml];
+      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, v);
+    }
+  }
+}
+
 template <int BM, int BN, int BK, int NST, int NW, bool PP = false>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN >= 256 * 128) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only
@@ -570,90 +666,185 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN >= 256 * 128) ? 2 : 1)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
-  const int mw = m0 + wm * (BM / WM) + 4 * h;     // + 16 i
-  const int pw = p0 + wn * (BN / WN) + r16;       // + 16 j
-  if (a.out_f32) {
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)(smem + (nk % NST) * STAGE));
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_igemm_halo_kernel -- 3x3 / stride 1 / pad 1 convolutions (forward and input gradient) with the
+// gathered operand kept as ONE halo'd pixel patch per 64-channel chunk instead of nine shifted copies.
+// The LDS-DMA kernel above is bound by the per-CU L2->LDS path (32 KB per 128x128x64 k-tile at ~29 B/clk,
+// DESIGN.md section 8); with stride 1 the nine taps of a chunk read the same pixels shifted by
+// d = (r-1) W + (s-1) in the flattened (n, h, w) index, so the pixel operand is fetched once per chunk:
+//   * patch = rows q0 .. q0 + PR - 1 of the flattened tensor, q0 = p0 - (W + 1), PR = 128 + 2W + 2
+//     (rounded to 8), 64 channels (128 B) per row, XOR-swizzled with the patch row; double-buffered
+//     across chunks, the next chunk's patch arrives in 8 slices behind the weight tiles of taps 0..7.
+//   * tap (r, s): fragment rows are the 16 consecutive patch rows starting at (W + 1) + d + pixel, read
+//     with the same ds_read_b128; a lane whose pixel has no such neighbour (image border: the shifted
+//     row belongs to the next line / image) is pointed at a 128-byte zero row instead -- one v_cndmask
+//     per fragment, the 9-bit validity mask per pixel is computed once in the prologue.
+//   * per k-tile the DMA traffic drops from 32 KB to 16 KB of weights + 1/9 of a ~20-46 KB patch.
+// LDS: [A stage 0][A stage 1][patch 0][patch 1][1 KiB dump: first 128 B = zero row; DMAs past the patch land here]
+// ------------------------------------------------------------------------------------------------
+template <int BM, int PI>
+__global__ __launch_bounds__(256, 2) void conv_igemm_halo_kernel(ConvArgs a, int PR, int npatch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BN = 128, BK = 64, NW = 4, WM = 2, WN = 2;
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+  constexpr int RSB = 128, RPI = 8;
+  constexpr int AI = BM / (NW * RPI);
+  constexpr int ASTAGE = BM * RSB;
+  constexpr int OOB = (int)0x80000000;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PATCH = PR * RSB;
+  const int NPI = PR / RPI;                    // DMA instructions per patch
+  char* sP = smem + 2 * ASTAGE;
+  char* sDump = sP + npatch * PATCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int P = a.Nimg * a.H * a.W;            // stride 1: output pixels = input pixels
+  const int K = 9 * a.C;
+  const int m0 = blockIdx.y * BM;
+  const int p0 = blockIdx.x * BN;
+  const int nchunk = a.C / BK;
+  const int nk = 9 * nchunk;
+  const bool fwd = a.mode == 0;
+
+  const int rsub = lane / 8;
+  const int lchunk = (lane % 8) ^ rsub;        // swz<64>(row) = row & 7, rows of an instruction start at a multiple of 8
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Mrows * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)P * a.C * 2), 0x00020000);
+  int a_off[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + (wave * AI + i) * RPI + rsub;
+    a_off[i] = m < a.Mrows ? (m * K + lchunk * 8) * 2 : OOB;
+  }
+  const int q0 = p0 - (a.W + 1);               // flattened pixel of patch row 0 (may be negative)
+  const int rowbytes = a.C * 2;
+
+  // ---- per-lane validity masks of the NT pixels whose fragments this lane reads (bit tap = r*3 + s)
+  uint32_t fmask[NT];
+  {
+    const int HW = a.H * a.W;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int p = pw + j * 16;
-      if (p >= P) continue;
+      const int p = p0 + wn * (BN / WN) + j * 16 + r16;
+      const int pc = p < P ? p : P - 1;
+      const int n = pc / HW;
+      const int rem = pc - n * HW;
+      const int ho = rem / a.W;
+      const int wo = rem - ho * a.W;
+      uint32_t vh = 0, vw = 0;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int m = mw + i * 16;
-        if (m >= a.Mrows) continue;
-        float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
-        if (a.splitk > 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
-        } else {
-          *(f32x4*)dst = acc[i][j];
-        }
+      for (int r = 0; r < 3; ++r) {
+        const int dd = fwd ? r - 1 : 1 - r;
+        vh |= ((unsigned)(ho + dd) < (unsigned)a.H) ? (1u << r) : 0u;
+        vw |= ((unsigned)(wo + dd) < (unsigned)a.W) ? (1u << r) : 0u;
       }
+      const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << 3 : 0u) | ((vh & 4u) ? vw << 6 : 0u);
+      fmask[j] = p < P ? mask : 0u;
     }
-    return;
   }
-  // bf16 output; the BatchNorm statistics are taken from the ROUNDED values (what the consumer reads)
-  float cs[MT][4], cq[MT][4];
+  if (tid < 32) ((float*)sDump)[tid] = 0.f;     // the zero row (visible after the first barrier)
+
+  // ---- DMA issue helpers
+  auto issueA = [&](int tap, int chunk, int stage) {
+    const int k0 = (tap * a.C + chunk * BK) * 2;
+    char* st = smem + stage * ASTAGE;
+#pragma unroll
+    for (int i = 0; i < AI; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(st + (wave * AI + i) * 1024), 16, a_off[i], k0, 0, 0);
+  };
+  // slice `slot` (0..7) of the patch of `chunk` into patch buffer `buf`: PI instructions per wave
+  auto issueP = [&](int slot, int chunk, int buf) {
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+      const int x = (slot * NW + wave) * PI + i;                 // instruction index in the patch (wave-uniform)
+      const int q = q0 + x * RPI + rsub;
+      const bool ok = x < NPI && (unsigned)q < (unsigned)P;
+      const int off = ok ? q * rowbytes + chunk * (BK * 2) + lchunk * 16 : OOB;
+      char* dst = x < NPI ? sP + buf * PATCH + x * 1024 : sDump;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)dst, 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
-  u16* yrow = (u16*)a.y + (size_t)pw * a.Mrows + mw;
-  auto store = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const bool okp = FULL || pw + j * 16 < P;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const bool ok = okp && (FULL || mw + i * 16 < a.Mrows);
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (__bf16)acc[i][j][e];
-          const float f = ok ? (float)o[e] : 0.f;
-          cs[i][e] += f;
-          cq[i][e] += f * f;
-        }
-        if (ok) *(bf16x4*)(yrow + (size_t)j * 16 * a.Mrows + i * 16) = o;
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const uint32_t ldsP = lds0 + 2 * ASTAGE;
+  const uint32_t zaddr = ldsP + (uint32_t)(npatch * PATCH);      // zero row
+  // prologue: weight tile 0 and the whole patch of chunk 0
+  issueA(0, 0, 0);
+#pragma unroll 1
+  for (int t = 0; t < 8; ++t) issueP(t, 0, 0);
+
+  int tap = 0, chunk = 0, tr = 0, ts = 0;
+  bool slice_prev = false;                       // a patch slice was issued in the previous iteration
+  for (int it = 0; it < nk; ++it) {
+    if (slice_prev) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // next weight tile, then (younger, so that it may stay in flight) one slice of the next chunk's patch
+    {
+      int ntap = tap + 1, nchk = chunk;
+      if (ntap == 9) {
+        ntap = 0;
+        ++nchk;
       }
+      if (it + 1 < nk) issueA(ntap, nchk, (it + 1) & 1);
+      slice_prev = tap < 8 && chunk + 1 < nchunk;
+      if (slice_prev) issueP(tap, chunk + 1, (chunk + 1) & 1);
     }
-  };
-  if (p0 + BN <= P && m0 + BM <= a.Mrows) store(std::true_type{});
-  else store(std::false_type{});
-  if (a.stats) {
-    // fused BatchNorm statistics: the 16 pixel lanes of a row are summed with DPP adds (no LDS
-    // round trips), lane r16 of row h keeps channel 16 (r16 >> 2) + 4h + (r16 & 3); the WN pixel
-    // halves of the workgroup meet in the LDS stage the last k-tile did not use (its readers all
-    // passed the last barrier), then ONE global atomic per channel and workgroup.
-    float sv = 0.f, qv = 0.f;
+    // fragment addresses of this tap
+    const int d = fwd ? (tr - 1) * a.W + (ts - 1) : (1 - tr) * a.W + (1 - ts);
+    const int rowb = (a.W + 1) + d + wn * (BN / WN) + r16;
+    const uint32_t pbase = ldsP + (uint32_t)((npatch > 1 ? (chunk & 1) : 0) * PATCH) + (uint32_t)(rowb * RSB);
+    const uint32_t abase = lds0 + (uint32_t)((it & 1) * ASTAGE) + (uint32_t)((wm * (BM / WM) + r16) * RSB);
+    bool okj[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int j = 0; j < NT; ++j) okj[j] = (fmask[j] >> tap) & 1u;
+    bf16x8 fa[2][MT], fb[2][NT];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float s = row16_sum(cs[i][e]), q = row16_sum(cq[i][e]);
-        if (r16 == i * 4 + e) {
-          sv = s;
-          qv = q;
-        }
-      }
-    float* red = (float*)(smem + (nk % NST) * STAGE);   // [WN][2][BM]
-    if (r16 < MT * 4) {
-      const int ml = wm * (BM / WM) + (r16 >> 2) * 16 + 4 * h + (r16 & 3);
-      red[(wn * 2 + 0) * BM + ml] = sv;
-      red[(wn * 2 + 1) * BM + ml] = qv;
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t ra = abase + (uint32_t)((((kk * 4 + h) ^ (r16 & 7))) << 4);
+      lds_read_frags<16 * RSB, 0>(fa[kk], ra, std::make_integer_sequence<int, MT>{});
+      const uint32_t rb = pbase + (uint32_t)((((kk * 4 + h) ^ (rowb & 7))) << 4);
+      [&]<int... J>(std::integer_sequence<int, J...>) {
+        ((fb[kk][J] = lds_read128_asm<J * 16 * RSB>(okj[J] ? rb : zaddr - (uint32_t)(J * 16 * RSB))), ...);
+      }(std::make_integer_sequence<int, NT>{});
     }
-    __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
-    for (int i = tid; i < 2 * BM; i += NW * 64) {
-      const int k = i / BM, ml = i - k * BM;
-      float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < WN; ++w) v += red[(w * 2 + k) * BM + ml];
-      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, v);
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT + NT) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16(fa[kk][i], fb[kk][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++ts == 3) {
+      ts = 0;
+      ++tr;
+    }
+    if (++tap == 9) {
+      tap = tr = ts = 0;
+      ++chunk;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)(smem + (nk & 1) * ASTAGE));
 #endif
 }
 
@@ -1060,6 +1251,23 @@ int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   return VLSFR_OK;
 }
 
+template <int BM, int PI>
+int launch_igemm_halo(const ConvArgs& a, int P, hipStream_t st) {
+  const int PR = ((128 + 2 * a.W + 2) + 7) & ~7;
+  const int npatch = a.C > 64 ? 2 : 1;
+  const int lds = 2 * BM * 128 + npatch * PR * 128 + 1024;
+  static int attr_lds = 0;
+  auto kern = conv_igemm_halo_kernel<BM, PI>;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return hip_fail(e, "conv_igemm_halo: hipFuncSetAttribute");
+    attr_lds = lds;
+  }
+  dim3 grid((P + 127) / 128, (a.Mrows + BM - 1) / BM, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, PR, npatch);
+  return VLSFR_OK;
+}
+
 template <int BM, int BN>
 void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
@@ -1075,7 +1283,15 @@ int run_igemm(ConvArgs a, hipStream_t st) {
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
   const bool glds_ok = g_use_glds && a.C % 64 == 0 && a.R * a.S <= 9 && (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30) &&
                        (size_t)a.Mrows * a.R * a.S * a.C < (1ull << 30);
-  if (glds_ok) {
+  const bool halo_ok = (g_use_halo == 2 || (g_use_halo == 1 && a.Mrows < 128)) && glds_ok && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.splitk == 1 &&
+                       !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.W <= 112 && a.H >= 2 && P >= 128;
+  if (halo_ok) {
+    int rc;
+    const bool pi2 = (128 + 2 * a.W + 2 + 7) / 8 > 32;
+    if (a.Mrows >= 128) rc = pi2 ? launch_igemm_halo<128, 2>(a, P, st) : launch_igemm_halo<128, 1>(a, P, st);
+    else rc = pi2 ? launch_igemm_halo<64, 2>(a, P, st) : launch_igemm_halo<64, 1>(a, P, st);
+    if (rc != VLSFR_OK) return rc;
+  } else if (glds_ok) {
     int rc;
     const bool big = a.Mrows >= 128;
     if (g_use_glds == 1) rc = big ? launch_igemm_glds<128, 128, 64, 4>(a, P, st) : launch_igemm_glds<64, 128, 64, 4>(a, P, st);
@@ -1121,6 +1337,10 @@ void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_halo")) {
+    g_use_halo = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "conv_dbg")) {
