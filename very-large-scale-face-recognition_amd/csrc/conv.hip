@@ -347,24 +347,42 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
-  u16* yrow = (u16*)a.y + (size_t)pw * a.Mrows + mw;
+  // 16-byte stores: rows h and h ^ 1 of the MFMA layout hold channels 4h..4h+3 and 4h+4..4h+7 of the same
+  // pixel, so v_permlane16_swap hands the even rows both halves of pixel tile j and the odd rows both
+  // halves of tile j + 1 -- 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail of a workgroup
+  // is issue-bound, not bandwidth-bound).
+  static_assert(NT % 2 == 0, "pixel tiles are stored in pairs");
+  const bool odd = h & 1;
+  u16* yrow = (u16*)a.y + (size_t)pw * a.Mrows + (mw - 4 * (h & 1));
   auto store = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const bool okp = FULL || pw + j * 16 < P;
+    for (int jp = 0; jp < NT / 2; ++jp) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const bool ok = okp && (FULL || mw + i * 16 < a.Mrows);
-        bf16x4 o;
+        uint32_t w[2][2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (__bf16)acc[i][j][e];
-          const float f = ok ? (float)o[e] : 0.f;
-          cs[i][e] += f;
-          cq[i][e] += f * f;
+        for (int t = 0; t < 2; ++t) {
+          const int j = 2 * jp + t;
+          const bool ok = FULL || (pw + j * 16 < P && mw + i * 16 < a.Mrows);
+          bf16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (__bf16)acc[i][j][e];
+            const float f = ok ? (float)o[e] : 0.f;
+            cs[i][e] += f;
+            cq[i][e] += f * f;
+          }
+          const uint2 u = __builtin_bit_cast(uint2, o);
+          w[t][0] = u.x;
+          w[t][1] = u.y;
         }
-        if (ok) *(bf16x4*)(yrow + (size_t)j * 16 * a.Mrows + i * 16) = o;
+        const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+        const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        const int j = 2 * jp + (odd ? 1 : 0);
+        const bool okst = FULL || (pw + j * 16 < P && mw - 4 * (h & 1) + i * 16 < a.Mrows);
+        if (okst) *(uint4*)(yrow + (size_t)j * 16 * a.Mrows + i * 16) = v;
       }
     }
   };
@@ -405,7 +423,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
 }
 
 template <int BM, int BN, int BK, int NST, int NW, bool PP = false>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && BM * BN >= 256 * 128) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
+__global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW == 8 && BM * BN <= 128 * 128)) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only
   // wave grid WM x WN (NW waves): each wave keeps (BM / WM) x (BN / WN) of the tile; the 8-wave
   // 256 x 128 / 128 x 256 tiles raise the FLOPs per byte a CU has to pull from L2 by a third over
@@ -1316,6 +1334,8 @@ int run_igemm(ConvArgs a, hipStream_t st) {
       rc = a.Mrows >= 256 ? launch_igemm_glds<256, 128, 64, 2, 8>(a, P, st)
            : big          ? launch_igemm_glds<128, 256, 64, 2, 8>(a, P, st)
                           : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 12)   // 128x128 tile on 8 waves (64x32 each): half the per-wave instruction stream, 4 waves per SIMD
+      rc = big ? launch_igemm_glds<128, 128, 64, 2, 8>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
