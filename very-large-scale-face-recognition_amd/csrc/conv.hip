@@ -691,9 +691,10 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
 // ------------------------------------------------------------------------------------------------
 // conv_igemm_halo_kernel -- 3x3 / stride 1 / pad 1 convolutions (forward and input gradient) with the
 // gathered operand kept as ONE halo'd pixel patch per 64-channel chunk instead of nine shifted copies.
-// The LDS-DMA kernel above is bound by the per-CU L2->LDS path (32 KB per 128x128x64 k-tile at ~29 B/clk,
-// DESIGN.md section 8); with stride 1 the nine taps of a chunk read the same pixels shifted by
-// d = (r-1) W + (s-1) in the flattened (n, h, w) index, so the pixel operand is fetched once per chunk:
+// Written to test whether the per-CU L2->LDS volume (32 KB per 128x128x64 k-tile) bounds the LDS-DMA kernel
+// above: with stride 1 the nine taps of a chunk read the same pixels shifted by d = (r-1) W + (s-1) in the
+// flattened (n, h, w) index, so the pixel operand is fetched once per chunk.  Result: same
+// speed at 0.6x the volume -- the volume is not the bound; kept behind vlsfr_set_option("conv_halo", v).
 //   * patch = rows q0 .. q0 + PR - 1 of the flattened tensor, q0 = p0 - (W + 1), PR = 128 + 2W + 2
 //     (rounded to 8), 64 channels (128 B) per row, XOR-swizzled with the patch row; double-buffered
 //     across chunks, the next chunk's patch arrives in 8 slices behind the weight tiles of taps 0..7.
@@ -1336,6 +1337,8 @@ int run_igemm(ConvArgs a, hipStream_t st) {
                           : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     else if (g_use_glds == 12)   // 128x128 tile on 8 waves (64x32 each): half the per-wave instruction stream, 4 waves per SIMD
       rc = big ? launch_igemm_glds<128, 128, 64, 2, 8>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (g_use_glds == 13)   // 64-channel layers on 64 x 256 tiles (half the workgroups, prologue / epilogue amortised)
+      rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 256, 64, 2>(a, P, st);
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);

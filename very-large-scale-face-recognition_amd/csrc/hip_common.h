@@ -43,6 +43,44 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// v + the value of lane (lane ^ O), without LDS traffic: v_permlane32_swap / v_permlane16_swap across the
+// 16-lane rows (swap(v, v) returns (own, partner) in one half and (partner, own) in the other, so the sum of
+// the pair is own + partner in every lane), DPP row rotations inside a row.  For O < 16 the rotation adds
+// lane (lane + O) mod 16 -- used as a reduction butterfly (O = 8, 4, 2, 1 in that order) it yields the same
+// group sums as the xor butterfly.
+// (own, partner) of lane ^ 16 / lane ^ 32.  The swap instruction exchanges halves of TWO registers in place;
+// written as inline asm on two read-write operands because the builtin, fed the same value twice, came back
+// as r[0] + r[0] (scripts/probes/lane_steps.hip).  The s_nops cover the VALU-write -> permlane-read hazard the
+// compiler cannot see inside the asm.
+template <int O>
+__device__ __forceinline__ void lane_pair(float v, float& r0, float& r1) {
+  float x = v, y = v;
+  if constexpr (O == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+  r0 = x;
+  r1 = y;
+}
+template <int O>
+__device__ __forceinline__ float lane_step_sum(float v) {
+  if constexpr (O >= 16) {
+    float r0, r1;
+    lane_pair<O>(v, r0, r1);
+    return r0 + r1;
+  } else {
+    return v + dpp_mov<0x120 + O>(v);   // row_ror:O
+  }
+}
+template <int O>
+__device__ __forceinline__ float lane_step_max(float v) {
+  if constexpr (O >= 16) {
+    float r0, r1;
+    lane_pair<O>(v, r0, r1);
+    return fmaxf(r0, r1);
+  } else {
+    return fmaxf(v, dpp_mov<0x120 + O>(v));
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -70,8 +70,13 @@ __device__ __forceinline__ void block_reduce_to_replica(float (&v)[NV][8], const
     for (int n = 0; n < NV; ++n)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float t = m.active ? v[n][j] : 0.f;
-        for (int o = 32; o >= m.cg; o >>= 1) t += __shfl_xor(t, o, 64);
+        float t = m.active ? v[n][j] : 0.f;   // lanes l, l + cg, l + 2 cg, ... hold the same channel group
+        if (m.cg <= 32) t = lane_step_sum<32>(t);
+        if (m.cg <= 16) t = lane_step_sum<16>(t);
+        if (m.cg <= 8) t = lane_step_sum<8>(t);
+        if (m.cg <= 4) t = lane_step_sum<4>(t);
+        if (m.cg <= 2) t = lane_step_sum<2>(t);
+        if (m.cg <= 1) t = lane_step_sum<1>(t);
         v[n][j] = t;
       }
     if ((tid & 63) < m.cg) {
