@@ -114,6 +114,166 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
   }
 }
 
+// 3x3 / pad 1 specialisation (every depthwise layer of MobileFaceNet but the 7x7 global one): the 72
+// weights of the thread's 8 channels live in registers, the nine taps of a pixel are nine predicated
+// 16-byte loads issued together (no per-tap branches, no weight loads in the loop); stride and
+// direction are compile-time.  DGRAD: dx[ih, iw] = sum_{r,c} dy[(ih + 1 - r) / st, (iw + 1 - c) / st] w[r][c]
+// over the taps that divide.
+template <int STRIDE, bool DGRAD, bool STATS>
+__global__ __launch_bounds__(256) void dw3_kernel(DwArgs a) {
+  extern __shared__ float sh[];
+  const int cg = a.C / 8;
+  const int rpb = 256 / cg;
+  const int col = threadIdx.x % cg;
+  const int rl = threadIdx.x / cg;
+  const bool active = rl < rpb;
+  const int OH = DGRAD ? a.H : a.Ho, OW = DGRAD ? a.W : a.Wo;
+  const int IH = DGRAD ? a.Ho : a.H, IW = DGRAD ? a.Wo : a.W;
+  const int64_t P = (int64_t)a.N * OH * OW;
+  float wr[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wr[t][j] = a.w[(size_t)(col * 8 + j) * 9 + t];
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  if (active) {
+    const u16* in = a.in + col * 8;
+    for (int64_t p = (int64_t)blockIdx.x * rpb + rl; p < P; p += (int64_t)gridDim.x * rpb) {
+      const int n = (int)(p / (OH * OW));
+      const int rem = (int)(p - (int64_t)n * OH * OW);
+      const int oh = rem / OW, ow = rem - oh * OW;
+      uint4 v[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          int ih, iw;
+          bool ok;
+          if (!DGRAD) {
+            ih = oh * STRIDE - 1 + r;
+            iw = ow * STRIDE - 1 + c;
+            ok = true;
+          } else {
+            const int th = oh + 1 - r, tw = ow + 1 - c;
+            ok = STRIDE == 1 || !((th | tw) & 1);
+            ih = STRIDE == 1 ? th : th >> 1;
+            iw = STRIDE == 1 ? tw : tw >> 1;
+          }
+          ok = ok && (unsigned)ih < (unsigned)IH && (unsigned)iw < (unsigned)IW;
+          v[r * 3 + c] = ok ? *(const uint4*)(in + (((int64_t)n * IH + ih) * IW + iw) * a.C) : make_uint4(0, 0, 0, 0);
+        }
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const uint32_t* vw = (const uint32_t*)&v[t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += bf_lo(vw[j]) * wr[t][2 * j];
+          acc[2 * j + 1] += bf_hi(vw[j]) * wr[t][2 * j + 1];
+        }
+      }
+      uint4 o;
+      uint32_t* ow32 = (uint32_t*)&o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ow32[j] = pack2(acc[2 * j], acc[2 * j + 1]);
+      *(uint4*)(a.out + p * a.C + col * 8) = o;
+      if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f0 = bf_lo(ow32[j]), f1 = bf_hi(ow32[j]);
+          s[2 * j] += f0;
+          q[2 * j] += f0 * f0;
+          s[2 * j + 1] += f1;
+          q[2 * j + 1] += f1 * f1;
+        }
+      }
+    }
+  }
+  if (STATS) {
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sh[col * 8 + j], s[j]);
+        atomicAdd(&sh[a.C + col * 8 + j], q[j]);
+      }
+    }
+    __syncthreads();
+    float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
+  }
+}
+
+// 3x3 weight gradient in one pass: per output pixel one dy load and nine predicated x loads, 72 per-thread
+// accumulators, block reduction in LDS, one atomic per (channel, tap) and block.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw3_wgrad_kernel(const u16* dy, const u16* x, float* dw, int N, int H, int W, int C,
+                                                        int Ho, int Wo) {
+  extern __shared__ float sh[];   // [9][C]
+  const int cg = C / 8;
+  const int rpb = 256 / cg;
+  const int col = threadIdx.x % cg;
+  const int rl = threadIdx.x / cg;
+  const int64_t P = (int64_t)N * Ho * Wo;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  if (rl < rpb) {
+    const u16* xin = x + col * 8;
+    for (int64_t p = (int64_t)blockIdx.x * rpb + rl; p < P; p += (int64_t)gridDim.x * rpb) {
+      const int n = (int)(p / (Ho * Wo));
+      const int rem = (int)(p - (int64_t)n * Ho * Wo);
+      const int oh = rem / Wo, ow = rem - oh * Wo;
+      const uint4 dv = *(const uint4*)(dy + p * C + col * 8);
+      uint4 v[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int ih = oh * STRIDE - 1 + r, iw = ow * STRIDE - 1 + c;
+          const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+          v[r * 3 + c] = ok ? *(const uint4*)(xin + (((int64_t)n * H + ih) * W + iw) * C) : make_uint4(0, 0, 0, 0);
+        }
+      const uint32_t* dw32 = (const uint32_t*)&dv;
+      float d[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        d[2 * j] = bf_lo(dw32[j]);
+        d[2 * j + 1] = bf_hi(dw32[j]);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const uint32_t* vw = (const uint32_t*)&v[t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[t][2 * j] += d[2 * j] * bf_lo(vw[j]);
+          acc[t][2 * j + 1] += d[2 * j + 1] * bf_hi(vw[j]);
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < 9 * C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  if (rl < rpb) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&sh[t * C + col * 8 + j], acc[t][j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * C; i += 256) {
+    const int t = i / C, c = i - t * C;
+    atomicAdd(&dw[(size_t)c * 9 + t], sh[i]);
+  }
+}
+
 // dw[c][r][s] += sum over output pixels of dy[n,ho,wo,c] * x[n, ho*st - pad + r, wo*st - pad + s, c]
 // grid = (pixel chunks, k*k taps)
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const u16* dy, const u16* x, float* dw, int N, int H, int W,
@@ -188,8 +348,20 @@ int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, vo
   DwArgs a{(const u16*)x, w, (u16*)y, d->N, d->H, d->W, d->Cin, odim(d->H, d->R, d->stride, d->pad),
            odim(d->W, d->S, d->stride, d->pad), d->R, d->stride, d->pad, 0, stats};
   const int64_t P = (int64_t)a.N * a.Ho * a.Wo;
-  hipLaunchKernelGGL(dw_conv_kernel, dim3(dw_blocks(P, a.C)), dim3(256), stats ? 2 * a.C * sizeof(float) : 0,
-                     (hipStream_t)stream, a);
+  const dim3 grid(dw_blocks(P, a.C)), block(256);
+  const size_t shb = stats ? 2 * a.C * sizeof(float) : 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->R == 3 && d->pad == 1) {
+    if (d->stride == 1) {
+      if (stats) hipLaunchKernelGGL((dw3_kernel<1, false, true>), grid, block, shb, st, a);
+      else hipLaunchKernelGGL((dw3_kernel<1, false, false>), grid, block, shb, st, a);
+    } else {
+      if (stats) hipLaunchKernelGGL((dw3_kernel<2, false, true>), grid, block, shb, st, a);
+      else hipLaunchKernelGGL((dw3_kernel<2, false, false>), grid, block, shb, st, a);
+    }
+  } else {
+    hipLaunchKernelGGL(dw_conv_kernel, grid, block, shb, st, a);
+  }
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_fwd");
   return VLSFR_OK;
 }
@@ -201,7 +373,13 @@ int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w,
   DwArgs a{(const u16*)dy, w, (u16*)dx, d->N, d->H, d->W, d->Cin, odim(d->H, d->R, d->stride, d->pad),
            odim(d->W, d->S, d->stride, d->pad), d->R, d->stride, d->pad, 1, nullptr};
   const int64_t P = (int64_t)a.N * a.H * a.W;
-  hipLaunchKernelGGL(dw_conv_kernel, dim3(dw_blocks(P, a.C)), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(dw_blocks(P, a.C)), block(256);
+  if (d->R == 3 && d->pad == 1) {
+    if (d->stride == 1) hipLaunchKernelGGL((dw3_kernel<1, true, false>), grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dw3_kernel<2, true, false>), grid, block, 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(dw_conv_kernel, grid, block, 0, (hipStream_t)stream, a);
+  }
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_dgrad");
   return VLSFR_OK;
 }
@@ -214,6 +392,17 @@ int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   const int64_t P = (int64_t)d->N * Ho * Wo;
   int nb = dw_blocks(P, d->Cin);
   if (nb > 512) nb = 512;
+  if (d->R == 3 && d->pad == 1) {
+    const size_t shb = 9 * d->Cin * sizeof(float);
+    if (d->stride == 1)
+      hipLaunchKernelGGL((dw3_wgrad_kernel<1>), dim3(nb), dim3(256), shb, (hipStream_t)stream, (const u16*)dy, (const u16*)x, dw,
+                         d->N, d->H, d->W, d->Cin, Ho, Wo);
+    else
+      hipLaunchKernelGGL((dw3_wgrad_kernel<2>), dim3(nb), dim3(256), shb, (hipStream_t)stream, (const u16*)dy, (const u16*)x, dw,
+                         d->N, d->H, d->W, d->Cin, Ho, Wo);
+    VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad");
+    return VLSFR_OK;
+  }
   hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nb, d->R * d->S), dim3(256), d->Cin * sizeof(float), (hipStream_t)stream,
                      (const u16*)dy, (const u16*)x, dw, d->N, d->H, d->W, d->Cin, Ho, Wo, d->R, d->stride, d->pad);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad");
