@@ -25,6 +25,10 @@
 
 using namespace vlsfr;
 
+namespace vlsfr {
+extern int g_dw_wgrad_blocks;   // csrc/dw.hip
+}
+
 namespace {
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around
@@ -1360,6 +1364,10 @@ void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "dw_wgrad_blocks")) {
+    vlsfr::g_dw_wgrad_blocks = value > 0 ? value : 256;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "conv_halo")) {

@@ -9,6 +9,10 @@
 
 using namespace vlsfr;
 
+namespace vlsfr {
+int g_dw_wgrad_blocks = 256;   // "dw_wgrad_blocks": workgroups of the one-pass depthwise weight gradient (all add into the same 9*C addresses)
+}
+
 namespace {
 
 constexpr int REPL = VLSFR_BN_REPL;
@@ -261,7 +265,25 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const u16* dy, const u16
   }
   for (int i = threadIdx.x; i < 9 * C; i += 256) sh[i] = 0.f;
   __syncthreads();
-  if (rl < rpb) {
+  // lanes l, l + cg, l + 2 cg, ... of a wave hold the same channel group: sum them in registers first
+  // (permlane swaps / DPP rotations), then one LDS atomic per value from the first cg lanes
+  const bool pow2 = (cg & (cg - 1)) == 0 && cg <= 32;
+  if (pow2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = rl < rpb ? acc[t][j] : 0.f;
+        if (cg <= 32) v = lane_step_sum<32>(v);
+        if (cg <= 16) v = lane_step_sum<16>(v);
+        if (cg <= 8) v = lane_step_sum<8>(v);
+        if (cg <= 4) v = lane_step_sum<4>(v);
+        if (cg <= 2) v = lane_step_sum<2>(v);
+        if (cg <= 1) v = lane_step_sum<1>(v);
+        acc[t][j] = v;
+      }
+  }
+  if (pow2 ? (threadIdx.x & 63) < cg : rl < rpb) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -391,8 +413,8 @@ int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   const int Ho = odim(d->H, d->R, d->stride, d->pad), Wo = odim(d->W, d->S, d->stride, d->pad);
   const int64_t P = (int64_t)d->N * Ho * Wo;
   int nb = dw_blocks(P, d->Cin);
-  if (nb > 512) nb = 512;
   if (d->R == 3 && d->pad == 1) {
+    if (nb > vlsfr::g_dw_wgrad_blocks) nb = vlsfr::g_dw_wgrad_blocks;
     const size_t shb = 9 * d->Cin * sizeof(float);
     if (d->stride == 1)
       hipLaunchKernelGGL((dw3_wgrad_kernel<1>), dim3(nb), dim3(256), shb, (hipStream_t)stream, (const u16*)dy, (const u16*)x, dw,
@@ -403,6 +425,7 @@ int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
     VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad");
     return VLSFR_OK;
   }
+  if (nb > 512) nb = 512;
   hipLaunchKernelGGL(dw_wgrad_kernel, dim3(nb, d->R * d->S), dim3(256), d->Cin * sizeof(float), (hipStream_t)stream,
                      (const u16*)dy, (const u16*)x, dw, d->N, d->H, d->W, d->Cin, Ho, Wo, d->R, d->stride, d->pad);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad");
