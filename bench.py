@@ -157,7 +157,7 @@ def main():
     sched.update(0, 0.0)
     step_model = model
     if world > 1:
-        sharded = args.pool == "sharded" and Q % world == 0 and args.loss != "SV"
+        sharded = args.pool == "sharded" and Q % world == 0
         step_model = ShardedFFC(model, dist) if sharded else DataParallelFFC(model, dist)
     rng = np.random.default_rng(1234 + rank)
     B = args.batch

@@ -153,13 +153,27 @@ size_t vlsfr_head_workspace_bytes(const vlsfr_head_cfg* cfg);
  * per row and variant M (log2 units), L, O[D] (unnormalised), the target terms T[D] / zt if it owns
  * the label slot, and its local top-k hard-negative candidates (value, global slot).  The ranks
  * combine with all-reduce(max) on M and all-reduce(sum) on the rescaled (O, T, L, zt)
- * (head.py ShardedDcpHead).  AM / Arc only. */
+ * (head.py ShardedDcpHead).  AM / Arc; SV goes through the two calls below. */
 int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
                              const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
                              const int32_t* src2, int32_t n_special, int32_t n_pos, float* out_M /*[B,2]*/,
                              float* out_L /*[B,2]*/, float* out_zt /*[B,2]*/, float* out_O /*[B,2,D]*/,
                              float* out_T /*[B,2,D]*/, float* cand_val /*[B,2,10]*/, int32_t* cand_col /*[B,2,10]*/,
                              void* workspace, size_t workspace_bytes, void* stream);
+/* SV under the sharded pool (ffc.py:118-127: columns with cos > gt - margin are "hard" and become t*cos + t - 1):
+ * the threshold of a row is known on the rank that owns its label slot.  vlsfr_head_shard_sv_thr writes this rank's
+ * view thr_out[2][B] (variant-major; -3e38 where the label slot is another rank's, +3e38 for outlier rows); after an
+ * all-reduce(max) over the ranks the result goes to vlsfr_head_shard_partial_sv, otherwise identical to
+ * vlsfr_head_shard_partial (one sweep per variant). */
+int vlsfr_head_shard_sv_thr(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                            const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                            const int32_t* src2, int32_t n_special, float* thr_out /*[2,B]*/, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int vlsfr_head_shard_partial_sv(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                                const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                                const int32_t* src2, int32_t n_special, int32_t n_pos, const float* sv_thr /*[2,B] global*/,
+                                float* out_M, float* out_L, float* out_zt, float* out_O, float* out_T, float* cand_val,
+                                int32_t* cand_col, void* workspace, size_t workspace_bytes, void* stream);
 /* T[row, v, :] += sel_w * class vector for the globally selected hard negatives this rank owns */
 int vlsfr_head_outlier_accum(const vlsfr_head_cfg* cfg, const float* g, const float* queue,
                              const int32_t* special_col, const int32_t* src1, const int32_t* src2,

@@ -222,7 +222,12 @@ class _SimComm(object):
 def _sharded_pass(shards, p, g, pl, gl, trans):
     """Drives `world` simulated ranks through partial -> combine -> finish in lockstep."""
     world = len(shards)
-    sts = [h.partial(p, g, pl, gl, trans) for h in shards]
+    sts = [h.begin(p, g, pl, gl, trans) for h in shards]
+    if sts[0]["thr"] is not None:                     # SV: all-reduce(max) of the hard-example thresholds
+        thr = torch.stack([s["thr"] for s in sts]).max(0).values
+        for s in sts:
+            s["thr"] = thr.clone()
+    sts = [h.sweep(s) for h, s in zip(shards, sts)]
     sim = _SimComm(world)
 
     class Comm(object):            # replays one rank's combine() against pre-computed collective results
@@ -250,7 +255,7 @@ def _sharded_pass(shards, p, g, pl, gl, trans):
     return outs
 
 
-@pytest.mark.parametrize("loss_type,margin,n_id", [("Arc", 0.5, 1500), ("AM", 0.4, 6000)])
+@pytest.mark.parametrize("loss_type,margin,n_id", [("Arc", 0.5, 1500), ("AM", 0.4, 6000), ("SV", 0.35, 1500), ("SV", 0.35, 6000)])
 @pytest.mark.parametrize("world", [2, 4])
 def test_identity_sharded_head_equals_single_pool(loss_type, margin, n_id, world):
     """The identity-sharded pool (each rank owns Q / world slots, softmax state combined with

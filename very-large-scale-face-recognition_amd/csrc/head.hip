@@ -395,6 +395,30 @@ __global__ __launch_bounds__(256) void head_special_kernel(SpecialArgs a) {
   }
 }
 
+// Sharded SV: the threshold of a row is known on the rank that owns its label slot; the others report -3e38
+// (outlier rows: +3e38 everywhere), so an all-reduce(max) over the ranks yields the global thresholds.
+__global__ void head_sv_thr_shard_kernel(const int32_t* pool_label, const int32_t* special_col, int n_special, int B,
+                                         const float* cos1, const float* cos2, float margin, int slot_lo, int Qs,
+                                         float* thr1, float* thr2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int t = pool_label[i];
+  float g1 = 3.0e38f, g2 = 3.0e38f;
+  if (t >= 0) {
+    g1 = g2 = -3.0e38f;
+    if (t >= slot_lo && t < slot_lo + Qs) {
+      for (int s = 0; s < n_special; ++s)
+        if (special_col[s] == t) {
+          g1 = cos1[(size_t)i * n_special + s] - margin;
+          g2 = cos2[(size_t)i * n_special + s] - margin;
+          break;
+        }
+    }
+  }
+  thr1[i] = g1;
+  thr2[i] = g2;
+}
+
 // SV hard-example thresholds gt - margin per row and variant (ffc.py:121-122)
 __global__ void head_sv_thr_kernel(const int32_t* pool_label, const int32_t* special_col, int n_special, int B,
                                    const float* cos1, const float* cos2, float margin, float* thr1, float* thr2) {
@@ -653,6 +677,7 @@ struct ShardFinishArgs {
   float* out_T;        // [B, 2, D]
   float* cand_val;     // [B, 2, KTOP]
   int32_t* cand_col;   // [B, 2, KTOP] global slot ids (-1 = none)
+  const float* sv_thr; // SV: [2][Bp] GLOBAL hard-example thresholds gt - margin (max over ranks), else nullptr
 };
 
 __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs sa) {
@@ -701,10 +726,24 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       const float* cs = (v == 0 ? a.cos1 : a.cos2) + (size_t)i * a.n_special;
       const int32_t* src = (v == 0 ? a.src1 : a.src2);
       float tm = 0.f, dtm = 0.f;
+      // SV (ffc.py:118-127): hard columns (cos > gt - margin, threshold global over the ranks) become t*cos + t - 1
+      const float thr = a.loss_type == 2 ? sa.sv_thr[(size_t)v * a.Bp + i] : 3.0e38f;
+      auto cmod = [&](int s) -> float {
+        if (s == st) return tm;
+        const float c = cs[s];
+        return (a.loss_type == 2 && c > thr) ? a.sv_t * c + a.sv_t - 1.f : c;
+      };
+      auto cfac = [&](int s) -> float {
+        if (s == st) return dtm;
+        return (a.loss_type == 2 && cs[s] > thr) ? a.sv_t : 1.f;
+      };
       if (st >= 0) {
         const float gt = cs[st];
         if (a.loss_type == 0) {
           tm = gt - a.margin;
+          dtm = 1.f;
+        } else if (a.loss_type == 2) {
+          tm = (gt > a.margin) ? gt - a.margin : gt;         // ffc.py:123
           dtm = 1.f;
         } else {
           const float sn = sqrtf(1.f - gt * gt);
@@ -715,7 +754,7 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       float mx = NEG_BIG;
       for (int c = tid; c < a.n_chunks; c += 256) mx = fmaxf(mx, a.part_m[v][(size_t)c * a.Bp + i]);
       for (int s = tid; s < a.n_special; s += 256)
-        if (owned(s)) mx = fmaxf(mx, (s == st ? tm : cs[s]) * qs);
+        if (owned(s)) mx = fmaxf(mx, cmod(s) * qs);
       const float M = block_max(mx);
       float lsum = 0.f;
       for (int c = tid; c < a.n_chunks; c += 256) {
@@ -724,7 +763,7 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
         lsum += w * a.part_l[v][(size_t)c * a.Bp + i];
       }
       for (int s = tid; s < a.n_special; s += 256)
-        if (owned(s)) lsum += exp2f((s == st ? tm : cs[s]) * qs - M);
+        if (owned(s)) lsum += exp2f(cmod(s) * qs - M);
       const float L = block_sum(lsum);
       float* O = sa.out_O + ((size_t)i * 2 + v) * D;
       float* T = sa.out_T + ((size_t)i * 2 + v) * D;
@@ -737,7 +776,7 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       __syncthreads();
       for (int s = tid; s < a.n_special; s += 256) {
         const bool own = owned(s);
-        wts[s] = own ? exp2f((s == st ? tm : cs[s]) * qs - M) * (s == st ? dtm : 1.f) : 0.f;
+        wts[s] = own ? exp2f(cmod(s) * qs - M) * cfac(s) : 0.f;
         // columns of other ranks get weight 0 and a harmless in-range address (their g row or slot 0)
         vptr[s] = special_vec(a.g, a.queue, a.Q, D, own ? a.special_col[s] - lo : 0, own ? src[s] : -1);
       }
@@ -1112,18 +1151,20 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   return VLSFR_OK;
 }
 
-int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
                              const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
                              const int32_t* src2, int32_t n_special, int32_t n_pos, float* out_M, float* out_L,
                              float* out_zt, float* out_O, float* out_T, float* cand_val, int32_t* cand_col,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+                             void* workspace, size_t workspace_bytes, void* stream, const float* sv_thr) {
   Plan pl;
   int rc = make_plan(cfg, &pl);
   if (rc != VLSFR_OK) return rc;
   if (!p || !g || !queue || !pool_label || !out_M || !out_L || !out_zt || !out_O || !out_T || !cand_val || !cand_col ||
       !workspace)
     return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: null argument");
-  if (cfg->loss_type == 2) return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: SV is not covered by the sharded head yet");
+  const bool sv = cfg->loss_type == 2;
+  if (sv && !sv_thr)
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: SV needs the global thresholds (vlsfr_head_shard_sv_thr + all-reduce(max), then vlsfr_head_shard_partial_sv)");
   const int B = cfg->B, D = cfg->D;
   if (n_special < 0 || n_special > 3 * B || (n_special > 0 && (!special_col || !src1 || !src2)))
     return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: bad special-column table");
@@ -1150,20 +1191,31 @@ int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const fl
   a.pool_label = pool_label;
   a.qscale = cfg->scale * LOG2E;
   a.sv_t = 1.2f;
-  a.sv_thr = nullptr;
-  a.part_m = (float*)(ws + pl.off_m);
-  a.part_l = (float*)(ws + pl.off_l);
-  a.part_o = (float*)(ws + pl.off_o);
+  float* thr = (float*)(ws + pl.off_thr);
+  const size_t rowsz = (size_t)pl.n_chunks * pl.Bp;
+  if (sv) {   // caller layout [2][B] -> workspace layout [2][Bp]
+    for (int v = 0; v < 2; ++v) {
+      hipError_t e = hipMemcpyAsync(thr + (size_t)v * pl.Bp, sv_thr + (size_t)v * B, (size_t)B * sizeof(float),
+                                    hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return hip_fail(e, "vlsfr_head_shard_partial_sv: threshold copy");
+    }
+  }
   a.topk_val = (float*)(ws + pl.off_tv);
   a.topk_idx = (int32_t*)(ws + pl.off_ti);
   a.Bp = pl.Bp;
   a.n_rowblk = pl.n_rowblk;
   a.slot_lo = cfg->slot_lo;
-  const bool topk = n_pos < B;
   const dim3 grid(pl.n_chunks * pl.n_rowblk);
-  rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, false, grid, st)
-                    : dispatch_sweep<false>(pl.DP, a, topk, false, grid, st);
-  if (rc != VLSFR_OK) return rc;
+  for (int set = 0; set < pl.n_sets; ++set) {   // SV: one sweep per variant (the threshold differs)
+    a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
+    a.part_l = (float*)(ws + pl.off_l) + set * rowsz;
+    a.part_o = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
+    a.sv_thr = sv ? thr + (size_t)set * pl.Bp : nullptr;
+    const bool topk = n_pos < B && set == 0;    // top-k uses raw cosines: variant independent
+    rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st)
+                      : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
+    if (rc != VLSFR_OK) return rc;
+  }
   ShardFinishArgs sf;
   FinishArgs& f = sf.f;
   f.g = g;
@@ -1182,9 +1234,10 @@ int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const fl
   f.cos1 = cos1;
   f.cos2 = cos2;
   for (int v = 0; v < 2; ++v) {
-    f.part_m[v] = a.part_m;
-    f.part_l[v] = a.part_l;
-    f.part_o[v] = a.part_o;
+    const int set = sv ? v : 0;
+    f.part_m[v] = (float*)(ws + pl.off_m) + set * rowsz;
+    f.part_l[v] = (float*)(ws + pl.off_l) + set * rowsz;
+    f.part_o[v] = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
   }
   f.topk_val = a.topk_val;
   f.topk_idx = a.topk_idx;
@@ -1205,6 +1258,7 @@ int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const fl
   sf.out_T = out_T;
   sf.cand_val = cand_val;
   sf.cand_col = cand_col;
+  sf.sv_thr = sv ? thr : nullptr;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
   const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + 16;
   if (lds_f > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish_shard: too many special columns for one LDS image");
@@ -1215,6 +1269,52 @@ int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const fl
   }
   hipLaunchKernelGGL(head_finish_shard_kernel, dim3(B), dim3(256), lds_f, st, sf);
   VLSFR_HIP_CHECK_LAUNCH("head_finish_shard launch");
+  return VLSFR_OK;
+}
+
+int vlsfr_head_shard_partial(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                             const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                             const int32_t* src2, int32_t n_special, int32_t n_pos, float* out_M, float* out_L,
+                             float* out_zt, float* out_O, float* out_T, float* cand_val, int32_t* cand_col,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  return shard_partial_impl(cfg, p, g, queue, pool_label, special_col, src1, src2, n_special, n_pos, out_M, out_L, out_zt,
+                            out_O, out_T, cand_val, cand_col, workspace, workspace_bytes, stream, nullptr);
+}
+
+int vlsfr_head_shard_partial_sv(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                                const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                                const int32_t* src2, int32_t n_special, int32_t n_pos, const float* sv_thr, float* out_M,
+                                float* out_L, float* out_zt, float* out_O, float* out_T, float* cand_val,
+                                int32_t* cand_col, void* workspace, size_t workspace_bytes, void* stream) {
+  return shard_partial_impl(cfg, p, g, queue, pool_label, special_col, src1, src2, n_special, n_pos, out_M, out_L, out_zt,
+                            out_O, out_T, cand_val, cand_col, workspace, workspace_bytes, stream, sv_thr);
+}
+
+int vlsfr_head_shard_sv_thr(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                            const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                            const int32_t* src2, int32_t n_special, float* thr_out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  Plan pl;
+  int rc = make_plan(cfg, &pl);
+  if (rc != VLSFR_OK) return rc;
+  if (!p || !g || !queue || !pool_label || !thr_out || !workspace)
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_sv_thr: null argument");
+  const int B = cfg->B;
+  if (n_special < 0 || n_special > 3 * B || (n_special > 0 && (!special_col || !src1 || !src2)))
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_sv_thr: bad special-column table");
+  if (workspace_bytes < pl.total) return fail(VLSFR_EINVAL, "vlsfr_head_shard_sv_thr: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  float* cos1 = (float*)(ws + pl.off_cos1);
+  float* cos2 = (float*)(ws + pl.off_cos2);
+  if (n_special > 0) {
+    SpecialArgs sa{p, g, queue, cfg->Q, B, cfg->D, n_special, special_col, src1, src2, cos1, cos2, cfg->slot_lo};
+    hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
+    VLSFR_HIP_CHECK_LAUNCH("head_special launch");
+  }
+  hipLaunchKernelGGL(head_sv_thr_shard_kernel, dim3((B + 255) / 256), dim3(256), 0, st, pool_label, special_col, n_special, B,
+                     cos1, cos2, cfg->margin, cfg->slot_lo, (int32_t)cfg->Q, thr_out, thr_out + B);
+  VLSFR_HIP_CHECK_LAUNCH("head_sv_thr_shard launch");
   return VLSFR_OK;
 }
 

@@ -192,8 +192,6 @@ class ShardedDcpHead(object):
     under the in-process simulator the single-GPU tests use."""
 
     def __init__(self, queue_shard, rank, world, Q_total, scale, margin, loss_type, precise=False, lru=None, qp=None):
-        if loss_type == "SV":
-            raise _lib.VlsfrError("the identity-sharded head covers AM / Arc (SV needs a per-variant threshold exchange)")
         self.L = _lib.lib()
         self.queue = queue_shard                 # [2, Qs, D] fp32 device
         self.rank, self.world = rank, world
@@ -212,7 +210,9 @@ class ShardedDcpHead(object):
         return HeadCfg(B, self.D, self.Qs, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
                        int(self.precise), 0, self.slot_lo, 0)
 
-    def partial(self, p_all, g_all, probe_label, gallery_label, transactional):
+    def begin(self, p_all, g_all, probe_label, gallery_label, transactional):
+        """Bookkeeping of one pass (identical on every rank) and, for SV, this rank's view of the hard-example
+        thresholds st["thr"] [2, B], which the caller all-reduces (max) over the ranks before `sweep`."""
         B = int(p_all.shape[0])
         tab, plan, undo = self._book.assign(probe_label, gallery_label, transactional)
         dev = p_all.device
@@ -223,24 +223,57 @@ class ShardedDcpHead(object):
             fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.POINTER(HeadCfg)]
             self._ws = torch.empty(fn(ctypes.byref(cfg)), dtype=torch.uint8, device=dev)
             self._ws_key = B
-        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
-        st = dict(M=f32(B, 2), L=f32(B, 2), zt=f32(B, 2), O=f32(B, 2, self.D), T=f32(B, 2, self.D),
-                  cand_val=f32(B, 2, 10), cand_col=torch.empty(B, 2, 10, dtype=torch.int32, device=dev))
         pd, gd = p_all.detach().float().contiguous(), g_all.detach().float().contiguous()
+        st = dict(tab_d=tab_d, plan=plan, cfg=cfg, pd=pd, gd=gd, transactional=transactional, thr=None,
+                  label=torch.from_numpy(tab[:B].copy()).to(dev))
+        if self.loss_type == "SV":
+            base = tab_d.data_ptr()
+            at = lambda k: ctypes.c_void_p(base + 4 * k * B)
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            thr = torch.empty(2, B, dtype=torch.float32, device=dev)
+            fn = self.L.vlsfr_head_shard_sv_thr
+            fn.restype = ctypes.c_int
+            _lib.check(fn(ctypes.byref(cfg), P(pd), P(gd), P(self.queue), at(0), at(1), at(4), at(7),
+                          ctypes.c_int32(plan.n_special), P(thr), P(self._ws), ctypes.c_size_t(self._ws.numel()),
+                          _stream_ptr()), "vlsfr_head_shard_sv_thr")
+            st["thr"] = thr
+        if transactional:
+            self._book.undo(plan, undo)
+        return st
+
+    def sweep(self, st):
+        """Local sweep over this rank's slots for all rows (st["thr"] must hold the GLOBAL thresholds for SV)."""
+        cfg, plan, tab_d, pd, gd = st["cfg"], st["plan"], st["tab_d"], st["pd"], st["gd"]
+        B, dev = int(pd.shape[0]), pd.device
+        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        st.update(M=f32(B, 2), L=f32(B, 2), zt=f32(B, 2), O=f32(B, 2, self.D), T=f32(B, 2, self.D),
+                  cand_val=f32(B, 2, 10), cand_col=torch.empty(B, 2, 10, dtype=torch.int32, device=dev))
         base, n = tab_d.data_ptr(), B
         at = lambda k: ctypes.c_void_p(base + 4 * k * n)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        fn = self.L.vlsfr_head_shard_partial
-        fn.restype = ctypes.c_int
-        _lib.check(fn(ctypes.byref(cfg), P(pd), P(gd), P(self.queue), at(0), at(1), at(4), at(7),
-                      ctypes.c_int32(plan.n_special), ctypes.c_int32(plan.n_pos), P(st["M"]), P(st["L"]), P(st["zt"]),
-                      P(st["O"]), P(st["T"]), P(st["cand_val"]), P(st["cand_col"]), P(self._ws),
-                      ctypes.c_size_t(self._ws.numel()), _stream_ptr()), "vlsfr_head_shard_partial")
-        if transactional:
-            self._book.undo(plan, undo)
-        st.update(tab_d=tab_d, plan=plan, cfg=cfg, pd=pd, gd=gd, transactional=transactional,
-                  label=torch.from_numpy(tab[:n].copy()).to(dev))
+        head = (ctypes.byref(cfg), P(pd), P(gd), P(self.queue), at(0), at(1), at(4), at(7),
+                ctypes.c_int32(plan.n_special), ctypes.c_int32(plan.n_pos))
+        tail = (P(st["M"]), P(st["L"]), P(st["zt"]), P(st["O"]), P(st["T"]), P(st["cand_val"]), P(st["cand_col"]),
+                P(self._ws), ctypes.c_size_t(self._ws.numel()), _stream_ptr())
+        if self.loss_type == "SV":
+            fn = self.L.vlsfr_head_shard_partial_sv
+            fn.restype = ctypes.c_int
+            thr = st["thr"].contiguous()
+            st["thr"] = thr
+            _lib.check(fn(*head, P(thr), *tail), "vlsfr_head_shard_partial_sv")
+        else:
+            fn = self.L.vlsfr_head_shard_partial
+            fn.restype = ctypes.c_int
+            _lib.check(fn(*head, *tail), "vlsfr_head_shard_partial")
         return st
+
+    def partial(self, p_all, g_all, probe_label, gallery_label, transactional, comm=None):
+        st = self.begin(p_all, g_all, probe_label, gallery_label, transactional)
+        if st["thr"] is not None:
+            if comm is None:
+                raise _lib.VlsfrError("ShardedDcpHead.partial: SV needs `comm` for the threshold all-reduce")
+            st["thr"] = comm.all_reduce_max(st["thr"])
+        return self.sweep(st)
 
     def combine(self, st, comm):
         """comm: all_reduce_max(t), all_reduce_sum(t), all_gather(t) -> [world, ...] (in place / returned)."""

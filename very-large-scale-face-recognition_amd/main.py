@@ -118,7 +118,7 @@ def train(conf, log=print):
     step_model = ffc_net
     if world > 1:
         from .parallel import DataParallelFFC, ShardedFFC
-        sharded = conf.queue_size % world == 0 and conf.loss_type != "SV"
+        sharded = conf.queue_size % world == 0
         step_model = ShardedFFC(ffc_net, dist) if sharded else DataParallelFFC(ffc_net, dist)
     rank = dist.get_rank() if dist else 0
     real_iter, loss = 0, None

@@ -14,7 +14,8 @@ The reference has no distributed code; the semantics defined here
         rows, and the softmax state is combined with all-reduce(max) + all-reduce(sum) of
         (O, T, L, zt) (head.ShardedDcpHead) — three small collectives per pass.
       - `DataParallelFFC`: replicated pool, every rank sweeps the whole pool for its own rows; no
-        softmax collective (kept for SV and as the A/B baseline).
+        softmax collective (the A/B baseline, and the fallback when the pool does not divide over the ranks).
+        SV under the sharded pool adds one small all-reduce(max) of the hard-example thresholds per pass.
 """
 import numpy as np
 import torch
@@ -153,7 +154,7 @@ class ShardedFFC(DataParallelFFC):
             p_all = self._gather_rows(p.detach())
         pl = self._gather_labels(probe_label)
         gl = self._gather_labels(gallery_label)
-        st = self.head.partial(p_all, g_all, pl, gl, transactional)
+        st = self.head.partial(p_all, g_all, pl, gl, transactional, comm=self.comm)
         st = self.head.combine(st, self.comm)
         loss, dP = self.head.finish(st)
         B = p.shape[0]
