@@ -199,7 +199,27 @@ def test_main_train_loop(tmp_path):
     net, loss = train(conf, log=logs.append)
     assert np.isfinite(float(loss.detach())) and len(logs) == 2
     ck = torch.load(os.path.join(str(tmp_path), "2.pt"), weights_only=False)
-    assert set(ck) == {"state_dict", "lru", "fc", "qp"}
+    assert set(ck) == {"state_dict", "lru", "fc", "qp", "resume"}      # the reference's four keys + the resume extras
     assert ck["fc"].shape == (2, 64, 32) and len(ck["qp"]) == 64 and len(ck["lru"]) == len(net.lru.state_dict())
     assert "layer1.0.conv1.weight" in ck["state_dict"]
     assert int(ck["state_dict"]["bn1.num_batches_tracked"]) == 12      # two probe forwards per iteration
+
+
+def test_resume_continues_the_run(tmp_path):
+    """Checkpoint -> `--resume`: a run interrupted after 2 of 4 iterations and resumed reaches the state
+    of the uninterrupted run -- LRU order and queue positions exactly, pool rows and loss within the run-to-run
+    noise of the bf16 / atomic-order arithmetic."""
+    from vlsfr_amd.main import parse_args, train
+    base = ["--net_type", "irtiny", "--feat_dim", "32", "--queue_size", "64", "--batch_size", "8", "--print_freq", "2",
+            "--iters_per_epoch", "4", "--num_class", "500"]
+    d1, d2 = tmp_path / "a", tmp_path / "b"
+    net_a, loss_a = train(parse_args(base + ["--saved_dir", str(d1)]), log=lambda *_: None)
+    net_b, loss_b = train(parse_args(base + ["--saved_dir", str(d2), "--resume", str(d1 / "1.pt")]), log=lambda *_: None)
+    assert net_a.lru.state_dict() == net_b.lru.state_dict()
+    assert net_a.queue_position_dict.to_dict() == net_b.queue_position_dict.to_dict()
+    la, lb = float(loss_a.detach()), float(loss_b.detach())
+    assert abs(la - lb) <= 2e-2 * abs(la)
+    assert float((net_a.queue - net_b.queue).abs().max()) < 0.05
+    wa = net_a.probe_net.state_dict()["layer1.0.conv1.weight"].float().cpu().numpy()
+    wb = net_b.probe_net.state_dict()["layer1.0.conv1.weight"].float().cpu().numpy()
+    assert rel_l2(wb, wa) < 2e-2

@@ -61,13 +61,44 @@ class SyntheticFaces(object):
             yield inst, inst_label, self._images(h), self._images(h), ids         # + id batch (main.py:43)
 
 
+def save_checkpoint(path, ffc_net, pool, optimizer=None, real_iter=0):
+    """The reference's dictionary (main.py:85: state_dict / lru / fc / qp) plus one extra key, `resume`, with what
+    the reference does not save but an exact continuation needs (EMA'd gallery weights, optimizer momenta)."""
+    torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict(),
+                'fc': pool.cpu(), 'qp': ffc_net.queue_position_dict.to_dict(),
+                'resume': {'gallery_state_dict': ffc_net.gallery_net.state_dict(), 'real_iter': int(real_iter),
+                           'optimizer': optimizer.state_dict() if optimizer is not None else None}}, path)
+
+
+def load_checkpoint(path, ffc_net, optimizer=None):
+    """Resume (the reference only saves): weights, pool, LRU order via LRU.restore (lru.py:113) and
+    queue positions.  A checkpoint written by the reference itself (no `resume` key) restarts the gallery net
+    as a copy of the probe net, as FFC.__init__ does (ffc.py:53-55).  Returns the iteration to continue from."""
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ffc_net.probe_net.load_state_dict(ck['state_dict'])
+    extra = ck.get('resume') or {}
+    ffc_net.gallery_net.load_state_dict(extra.get('gallery_state_dict') or ck['state_dict'])
+    with torch.no_grad():
+        ffc_net.queue.copy_(ck['fc'].to(ffc_net.queue.device))
+    state = ffc_net._state()
+    state.lru.clear()
+    state.lru.restore([tuple(kv) for kv in ck['lru']])
+    qp = ck['qp']
+    state.qp[:] = np.asarray([qp[i] for i in range(len(qp))], dtype=np.uint8)
+    if optimizer is not None and extra.get('optimizer') is not None:
+        optimizer.load_state_dict(extra['optimizer'])
+    return int(extra.get('real_iter', 0))
+
+
 def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_iter, lr_policy, lr_scheduler,
-                    max_epochs, world=1, log=print):
+                    max_epochs, world=1, log=print, skip=0):
     random.seed(cur_epoch)
     db_size = len(data)
     start = time.time()
     loss = None
     for batch_idx, (ins_images, instance_label, images1, images2, id_indexes) in enumerate(data):
+        if batch_idx < skip:                                                       # resumed inside this epoch
+            continue
         if lr_policy != 'ReduceLROnPlateau':
             lr_scheduler.update(None, batch_idx * 1.0 / db_size)                   # main.py:39-40
         inst1, inst2 = torch.chunk(ins_images, 2)                                  # main.py:53-54
@@ -95,9 +126,8 @@ def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_
             pool = step_model.gather_pool() if hasattr(step_model, 'gather_pool') else ffc_net.queue
             if conf.saved_dir and (world == 1 or torch.distributed.get_rank() == 0):
                 os.makedirs(conf.saved_dir, exist_ok=True)
-                torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict(),
-                            'fc': pool.cpu(), 'qp': ffc_net.queue_position_dict.to_dict()},
-                           os.path.join(conf.saved_dir, '%d.pt' % (real_iter // conf.print_freq)))
+                save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % (real_iter // conf.print_freq)), ffc_net, pool,
+                                optimizer, real_iter)
     return real_iter, loss
 
 
@@ -115,19 +145,25 @@ def train(conf, log=print):
                   conf.neg_margin, conf.pretrained_model_path, conf.num_class).cuda()          # main.py:116-117
     optim_config = load_config(conf.optim_config) if conf.optim_config else dict(OPTIM_CONFIG)
     optim, lr_scheduler = get_optim_scheduler([p for p in ffc_net.parameters() if p.requires_grad], optim_config)
+    start_iter = 0
+    if getattr(conf, "resume", ""):
+        start_iter = load_checkpoint(conf.resume, ffc_net, optim)      # before the pool is sharded over the ranks
     step_model = ffc_net
     if world > 1:
         from .parallel import DataParallelFFC, ShardedFFC
         sharded = conf.queue_size % world == 0
         step_model = ShardedFFC(ffc_net, dist) if sharded else DataParallelFFC(ffc_net, dist)
     rank = dist.get_rank() if dist else 0
-    real_iter, loss = 0, None
+    real_iter, loss = start_iter, None
     for epoch in range(optim_config['epochs']):                                    # main.py:134-140
+        if start_iter >= (epoch + 1) * conf.iters_per_epoch:
+            continue
         if optim_config['scheduler'] != 'ReduceLROnPlateau':
             lr_scheduler.update(epoch, 0.0)
         data = SyntheticFaces(conf.num_class, conf.batch_size, conf.iters_per_epoch, dev, seed=1000 * epoch + rank)
         real_iter, loss = train_one_epoch(data, ffc_net, step_model, optim, epoch + 1, conf, real_iter,
-                                          optim_config['scheduler'], lr_scheduler, optim_config['epochs'], world, log)
+                                          optim_config['scheduler'], lr_scheduler, optim_config['epochs'], world, log,
+                                          skip=max(0, start_iter - epoch * conf.iters_per_epoch))
     return ffc_net, loss
 
 
@@ -149,6 +185,7 @@ def parse_args(argv=None):
     conf.add_argument('--num_class', type=int, default=100000, help='identities of the synthetic dataset')
     conf.add_argument('--iters_per_epoch', type=int, default=100)
     conf.add_argument('--optim_config', type=str, default='', help='typed-JSON file in the format of config/optim_config')
+    conf.add_argument('--resume', type=str, default='', help='checkpoint written by this driver (or by the reference) to continue from')
     return conf.parse_args(argv)
 
 

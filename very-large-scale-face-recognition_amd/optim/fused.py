@@ -124,6 +124,8 @@ class FusedSGD(torch.optim.Optimizer):
                 st = self.state[p]
                 if "momentum_buffer" not in st:
                     st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif st["momentum_buffer"].stride() != p.stride():      # e.g. after load_state_dict: the kernel walks raw memory
+                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st["momentum_buffer"])
                 groups.append((p.data, p.grad, st["momentum_buffer"]))
             cache = self._caches.setdefault(gi, _TableCache())
             tab = cache.get(groups, ps[0].device)
