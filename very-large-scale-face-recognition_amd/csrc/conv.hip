@@ -305,6 +305,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_void_t;
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
 template <int OFF>
 __device__ __forceinline__ bf16x8 lds_read128_asm(uint32_t addr) {
   bf16x8 v;
@@ -426,8 +432,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   }
 }
 
-template <int BM, int BN, int BK, int NST, int NW, bool PP = false>
-__global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW == 8 && BM * BN <= 128 * 128)) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
+template <int BM, int BN, int BK, int NST, int NW, bool PP = false, bool SWP = false>
+__global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW == 8 && BM * BN <= 128 * 128) || SWP) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only
   // wave grid WM x WN (NW waves): each wave keeps (BM / WM) x (BN / WN) of the tile; the 8-wave
   // 256 x 128 / 128 x 256 tiles raise the FLOPs per byte a CU has to pull from L2 by a third over
@@ -572,7 +578,64 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   const int pre = nk < NST - 1 ? nk : NST - 1;
   for (int s = 0; s < pre; ++s) issue(s);
 
-  if constexpr (PP) {
+  if constexpr (SWP) {
+    // ---- software-pipelined schedule: the fragments of tile t live in registers while its 32 MFMAs run, and
+    // the 16 LDS reads of tile t + 1 are interleaved between those MFMAs (two fragment sets, swapped every
+    // tile), so a wave no longer pays "issue reads, wait for LDS, then multiply" per k-tile.  With tile t in
+    // registers its LDS stage is free as soon as every wave has read it: the DMA of tile t + 2 goes there,
+    // still two stages of LDS.  Per tile: vmcnt(0) (tile t + 1 landed) + barrier, DMA issue of tile t + 2,
+    // 2 x (16 MFMAs + 8 reads), lgkmcnt(0).
+    static_assert(NW == 4 && BK == 64 && NST == 2 && !PP, "software-pipelined variant: 4 waves, 64-deep tiles, 2 stages");
+    constexpr int NDMA = AI + BI;
+    bf16x8 fA[2][2][MT], fB[2][2][NT];   // [set][k-step][fragment]
+    auto rd_base = [&](int t, int kk) -> uint32_t {
+      return lds0 + (uint32_t)((t % NST) * STAGE) + (uint32_t)(r16 * RSB + (((kk * 4 + h) ^ swz<BK>(r16)) << 4));
+    };
+    const uint32_t offA = (uint32_t)(wm * (BM / WM) * RSB), offB = (uint32_t)(wn * (BN / WN) * RSB);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t rd = rd_base(0, kk);
+      lds_read_frags<16 * RSB, 0>(fA[0][kk], rd + offA, std::make_integer_sequence<int, MT>{});
+      lds_read_frags<16 * RSB, BM * RSB>(fB[0][kk], rd + offB, std::make_integer_sequence<int, NT>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int BPR = NT / MT;   // B fragments fetched per MFMA row (the A fragment of the row comes with them)
+    auto tile = [&]<int PAR>(int it, std::integral_constant<int, PAR>) {
+      const bool more = it + 1 < nk;
+      if (more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's slices of tile it + 1 have landed
+        __builtin_amdgcn_s_barrier();                         // ... everybody's; and every wave holds tile it in registers
+        if (it + 2 < nk) issue(it % NST);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint32_t rd = rd_base(it + 1, kk);
+        static_for<MT>([&](auto ic) {
+          constexpr int I = decltype(ic)::value;
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            fA[PAR ^ 1][kk][I] = lds_read128_asm<I * 16 * RSB>(rd + offA);
+            static_for<BPR>([&](auto jc) {
+              constexpr int J = I * BPR + decltype(jc)::value;
+              fB[PAR ^ 1][kk][J] = lds_read128_asm<BM * RSB + J * 16 * RSB>(rd + offB);
+            });
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[I][j] = mfma16(fA[PAR][kk][I], fB[PAR][kk][j], acc[I][j]);
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    for (int it = 0; it < nk; it += 2) {
+      tile(it, std::integral_constant<int, 0>{});
+      if (it + 1 < nk) tile(it + 1, std::integral_constant<int, 1>{});
+    }
+  } else if constexpr (PP) {
     // ---- ping-pong schedule (8 waves = two groups of one wave per SIMD, three 64-deep stages, one
     // workgroup per CU).  Phases alternate: while one group runs the 32 MFMAs of a k-tile from
     // registers, the other reads its fragments of the next tile from LDS and issues its slice of the
@@ -1259,11 +1322,11 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
 
 inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
-template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false>
+template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false, bool SWP = false>
 int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr_set = false;
-  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW, PP>;
+  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW, PP, SWP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "conv_igemm_glds: hipFuncSetAttribute");
@@ -1343,6 +1406,9 @@ int run_igemm(ConvArgs a, hipStream_t st) {
       rc = big ? launch_igemm_glds<128, 128, 64, 2, 8>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     else if (g_use_glds == 13)   // 64-channel layers on 64 x 256 tiles (half the workgroups, prologue / epilogue amortised)
       rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 256, 64, 2>(a, P, st);
+    else if (g_use_glds == 14)   // software-pipelined loop (fragments of tile t + 1 read between the MFMAs of tile t)
+      rc = big ? launch_igemm_glds<128, 128, 64, 2, 4, false, true>(a, P, st)
+               : launch_igemm_glds<64, 128, 64, 2, 4, false, true>(a, P, st);
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
