@@ -57,6 +57,18 @@ __device__ __forceinline__ RowMap row_map(int C) {
   return m;
 }
 
+// eight consecutive per-channel constants of a thread's channel group as two 16-byte loads (fill if the array is absent)
+__device__ __forceinline__ void load8(const float* arr, int c0, float fill, float (&o)[8]) {
+  if (arr) {
+    const float4 lo = *(const float4*)(arr + c0), hi = *(const float4*)(arr + c0 + 4);
+    o[0] = lo.x; o[1] = lo.y; o[2] = lo.z; o[3] = lo.w;
+    o[4] = hi.x; o[5] = hi.y; o[6] = hi.z; o[7] = hi.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fill;
+  }
+}
+
 // sums over the block of per-thread partials v[NV][8] into out[rep][NV][C]
 template <int NV>
 __device__ __forceinline__ void block_reduce_to_replica(float (&v)[NV][8], const RowMap& m, int C, float* sh,
@@ -199,9 +211,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
     const int c = m.col * 8 + j;
     sc[j] = sh[c];
     sf[j] = sh[C + c];
-    sl[j] = PRELU ? a.slope[c] : 1.f;
     v[0][j] = v[1][j] = 0.f;
   }
+  load8(PRELU ? a.slope : nullptr, m.col * 8, 1.f, sl);
   __syncthreads();   // sh is reused below
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
@@ -296,15 +308,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   // the loop accumulates sum dz, sum dz*x (RAW x) and sum dy*z over z <= 0; sum dz*xhat follows as
   // invstd * (sum dz*x - mean * sum dz) -- fewer per-channel constants in registers.  z = x*zs + zo is only
   // needed for the PReLU sign and slope gradient.
-  float v[3][8], zs[8], zo[8], sl[8];
+  float v[3][8], zs[8], zo[8], sl[8], c_is[8], c_mean[8];
+  {
+    float cg_[8], cb_[8];
+    load8(a.invstd, m.col * 8, 1.f, c_is);
+    load8(a.mean, m.col * 8, 0.f, c_mean);
+    load8(a.gamma, m.col * 8, 1.f, cg_);
+    load8(a.beta, m.col * 8, 0.f, cb_);
+    load8(PRELU ? a.slope : nullptr, m.col * 8, 1.f, sl);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = m.col * 8 + j;
-    v[0][j] = v[1][j] = v[2][j] = 0.f;
-    const float is = a.invstd[c], g = a.gamma ? a.gamma[c] : 1.f;
-    zs[j] = is * g;
-    zo[j] = (a.beta ? a.beta[c] : 0.f) - a.mean[c] * is * g;
-    sl[j] = PRELU ? a.slope[c] : 1.f;
+    for (int j = 0; j < 8; ++j) {
+      v[0][j] = v[1][j] = v[2][j] = 0.f;
+      zs[j] = c_is[j] * cg_[j];
+      zo[j] = cb_[j] - c_mean[j] * c_is[j] * cg_[j];
+    }
   }
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
@@ -341,9 +358,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {   // sum dz*xhat from the raw-x sum (linear, so it commutes with the reduction)
-    const int c = m.col * 8 + j;
-    const float is = a.invstd[c];
-    v[1][j] = is * (v[1][j] - a.mean[c] * v[0][j]);
+    v[1][j] = c_is[j] * (v[1][j] - c_mean[j] * v[0][j]);
   }
   block_reduce_to_replica<3>(v, m, C, sh, a.red);
 }
@@ -380,17 +395,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   // dx = k0*(dz - k1 - xhat*k2) = A*dz + Bx*x + Cc with xhat = x*invstd - mean*invstd folded in;
   // dz = dy * (z <= 0 ? slope : 1): As = A*slope
   float A[8], As[8], Bx[8], Cc[8], zs[8], zo[8];
+  {
+    float c_is[8], c_mean[8], cg_[8], cb_[8], csl[8];
+    load8(a.invstd, m.col * 8, 1.f, c_is);
+    load8(a.mean, m.col * 8, 0.f, c_mean);
+    load8(a.gamma, m.col * 8, 1.f, cg_);
+    load8(a.beta, m.col * 8, 0.f, cb_);
+    load8(PRELU ? a.slope : nullptr, m.col * 8, 1.f, csl);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = m.col * 8 + j;
-    const float k0 = sh[c], k1 = sh[C + c], k2 = sh[2 * C + c];
-    const float is = a.invstd[c], xo = -a.mean[c] * is, g = a.gamma ? a.gamma[c] : 1.f;
-    A[j] = k0;
-    As[j] = k0 * (PRELU ? a.slope[c] : 1.f);
-    Bx[j] = -k0 * k2 * is;
-    Cc[j] = -k0 * (k1 + k2 * xo);
-    zs[j] = is * g;
-    zo[j] = (a.beta ? a.beta[c] : 0.f) + xo * g;
+    for (int j = 0; j < 8; ++j) {
+      const int c = m.col * 8 + j;
+      const float k0 = sh[c], k1 = sh[C + c], k2 = sh[2 * C + c];
+      const float is = c_is[j], xo = -c_mean[j] * is, g = cg_[j];
+      A[j] = k0;
+      As[j] = k0 * csl[j];
+      Bx[j] = -k0 * k2 * is;
+      Cc[j] = -k0 * (k1 + k2 * xo);
+      zs[j] = is * g;
+      zo[j] = cb_[j] + xo * g;
+    }
   }
   const int64_t r0 = (int64_t)blockIdx.x * a.RB;
   const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
