@@ -47,7 +47,8 @@ int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // "conv_glds": 0 register-staged
 int g_use_halo = 0;          // "conv_halo": halo-patch kernel for 3x3 / stride-1 layers: 0 never (no end-to-end gain measured), 1 the 64-channel layers, 2 all
 int g_wgrad_glds = 1;        // "wgrad_glds": 1 LDS-DMA ring (conv_wgrad_glds_kernel), 0 register-staged kernel
 int g_wgrad_kt = 32;         // "wgrad_kt": pixels per k-tile of the register-staged weight-gradient kernel (32 or 64)
-int g_wgrad_target = 1024;   // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into
+int g_wgrad_target = 384;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
+                             // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
 std::vector<ProfRec> g_prof;
@@ -1453,7 +1454,7 @@ int vlsfr_set_option(const char* name, int32_t value) {
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "wgrad_target_wgs")) {
-    g_wgrad_target = value > 0 ? value : 1024;
+    g_wgrad_target = value > 0 ? value : 384;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "bn_block_kb")) {
