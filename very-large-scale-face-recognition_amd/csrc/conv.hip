@@ -404,22 +404,29 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     // round trips), lane r16 of row h keeps channel 16 (r16 >> 2) + 4h + (r16 & 3); the WN pixel
     // halves of the workgroup meet in the LDS stage the last k-tile did not use (its readers all
     // passed the last barrier), then ONE global atomic per channel and workgroup.
-    float sv = 0.f, qv = 0.f;
+    float* red = red_lds;   // [WN][2][BM]
+    constexpr int NR = (MT + 3) / 4;   // rounds of 16 (i, e) values: one value per pixel lane of the row
+    float sv[NR], qv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) sv[r] = qv[r] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float s = row16_sum(cs[i][e]), q = row16_sum(cq[i][e]);
-        if (r16 == i * 4 + e) {
-          sv = s;
-          qv = q;
+        if (r16 == (i & 3) * 4 + e) {
+          sv[i >> 2] = s;
+          qv[i >> 2] = q;
         }
       }
-    float* red = red_lds;   // [WN][2][BM]
-    if (r16 < MT * 4) {
-      const int ml = wm * (BM / WM) + (r16 >> 2) * 16 + 4 * h + (r16 & 3);
-      red[(wn * 2 + 0) * BM + ml] = sv;
-      red[(wn * 2 + 1) * BM + ml] = qv;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ni = MT - 4 * r < 4 ? MT - 4 * r : 4;
+      if (r16 < ni * 4) {
+        const int ml = wm * (BM / WM) + (4 * r + (r16 >> 2)) * 16 + 4 * h + (r16 & 3);
+        red[(wn * 2 + 0) * BM + ml] = sv[r];
+        red[(wn * 2 + 1) * BM + ml] = qv[r];
+      }
     }
     __syncthreads();
     float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
