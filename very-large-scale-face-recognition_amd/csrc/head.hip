@@ -465,6 +465,52 @@ struct FinishArgs {
   float* dP;                // [B, D]
 };
 
+// sum_s wts[s] * vptr[s][:] over the special columns (weights and class-vector addresses in LDS): wave w takes
+// columns w, w + 4, ..., every lane owns features lane + 64 k -- eight independent loads in flight per lane and a
+// quarter of the iterations of a "thread per feature, all columns in sequence" loop, which pays one memory latency
+// per column (0.77 us per special column and row measured).  The four per-wave sums meet in wsum[4][D] (LDS) and are
+// added in a fixed order: deterministic.
+__device__ __forceinline__ void combine_rows(const float* const* vptr, const float* wts, int n, int D, float* wsum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float accv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) accv[k] = 0.f;
+  for (int s = wave; s < n; s += 4) {
+    const float w = wts[s];
+    const float* vec = vptr[s];
+    float ld[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ld[k] = (lane + 64 * k < D) ? vec[lane + 64 * k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) accv[k] += w * ld[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (lane + 64 * k < D) wsum[wave * D + lane + 64 * k] = accv[k];
+  __syncthreads();
+}
+
+// the same over rows base + c * stride (the per-chunk partial O vectors of one probe row)
+__device__ __forceinline__ void combine_strided(const float* base, size_t stride, const float* wts, int n, int D, float* wsum) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float accv[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) accv[k] = 0.f;
+  for (int c = wave; c < n; c += 4) {
+    const float w = wts[c];
+    const float* vec = base + (size_t)c * stride;
+    float ld[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ld[k] = (lane + 64 * k < D) ? vec[lane + 64 * k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) accv[k] += w * ld[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (lane + 64 * k < D) wsum[wave * D + lane + 64 * k] = accv[k];
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int i = blockIdx.x;
@@ -476,6 +522,7 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
   float* wts = red + 16;                        // [max(n_chunks, n_special)] per-chunk / per-special weights
   const int nw_lds = a.n_chunks > a.n_special ? a.n_chunks : a.n_special;
   const float** vptr = (const float**)(wts + ((nw_lds + 1) & ~1));   // [n_special] class-vector address per special column
+  float* wsum = (float*)(vptr + a.n_special);                       // [4][D] per-wave partial sums
   const int label = a.pool_label[i];
   const float qs = a.scale * LOG2E;
   for (int d = tid; d < D; d += 256) dp[d] = 0.f;
@@ -557,11 +604,8 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
       if (tid == 0) a.row_loss[(size_t)i * 2 + v] = (LN2 * (M + log2f(L)) - zt) * inv_pos;
       // --- gradient: swept part
       const float gscale = a.scale * inv_pos / L;
-      for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-        for (int c = 0; c < a.n_chunks; ++c) acc += wts[c] * a.part_o[v][((size_t)c * a.Bp + i) * a.DP + d];
-        dp[d] += gscale * acc;
-      }
+      combine_strided(a.part_o[v] + (size_t)i * a.DP, (size_t)a.Bp * a.DP, wts, a.n_chunks, D, wsum);
+      for (int d = tid; d < D; d += 256) dp[d] += gscale * ((wsum[d] + wsum[D + d]) + (wsum[2 * D + d] + wsum[3 * D + d]));
       __syncthreads();
       // --- gradient: special columns (softmax weight times d logit / d cos) and the -1 of the target
       for (int s = tid; s < a.n_special; s += 256) {
@@ -582,11 +626,8 @@ __global__ __launch_bounds__(256) void head_finish_kernel(FinishArgs a) {
       __syncthreads();
       // thread per feature, loop over the special columns: weights and addresses come from LDS, so the
       // global loads of consecutive columns are independent and stay in flight together
-      for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-        for (int s = 0; s < a.n_special; ++s) acc += wts[s] * vptr[s][d];
-        dp[d] += acc;
-      }
+      combine_rows(vptr, wts, a.n_special, D, wsum);
+      for (int d = tid; d < D; d += 256) dp[d] += (wsum[d] + wsum[D + d]) + (wsum[2 * D + d] + wsum[3 * D + d]);
       __syncthreads();
     }
   } else {
@@ -690,7 +731,8 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
   float* red = (float*)smem;                    // [16]
   float* wts = red + 16;                        // [max(n_chunks, n_special)]
   const int nw_lds = a.n_chunks > a.n_special ? a.n_chunks : a.n_special;
-  const float** vptr = (const float**)(wts + ((nw_lds + 1) & ~1));   // [n_special]
+  const float** vptr = (const float**)(wts + ((nw_lds + 1) & ~1));
+  float* wsum = (float*)(vptr + a.n_special);   // [4][D] per-wave partial sums   // [n_special]
   const int label = a.pool_label[i];
   const float qs = a.scale * LOG2E;
   const int lo = sa.slot_lo, hi = sa.slot_lo + (int)a.Q;
@@ -767,10 +809,9 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       const float L = block_sum(lsum);
       float* O = sa.out_O + ((size_t)i * 2 + v) * D;
       float* T = sa.out_T + ((size_t)i * 2 + v) * D;
+      combine_strided(a.part_o[v] + (size_t)i * a.DP, (size_t)a.Bp * a.DP, wts, a.n_chunks, D, wsum);
       for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-        for (int c = 0; c < a.n_chunks; ++c) acc += wts[c] * a.part_o[v][((size_t)c * a.Bp + i) * a.DP + d];
-        O[d] = acc;
+        O[d] = (wsum[d] + wsum[D + d]) + (wsum[2 * D + d] + wsum[3 * D + d]);
         T[d] = 0.f;
       }
       __syncthreads();
@@ -781,11 +822,9 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
         vptr[s] = special_vec(a.g, a.queue, a.Q, D, own ? a.special_col[s] - lo : 0, own ? src[s] : -1);
       }
       __syncthreads();
-      for (int d = tid; d < D; d += 256) {
-        float acc = 0.f;
-        for (int s = 0; s < a.n_special; ++s) acc += wts[s] * vptr[s][d];
-        O[d] += acc;
-      }
+      combine_rows(vptr, wts, a.n_special, D, wsum);
+      for (int d = tid; d < D; d += 256) O[d] += (wsum[d] + wsum[D + d]) + (wsum[2 * D + d] + wsum[3 * D + d]);
+      __syncthreads();
       if (st >= 0) {
         const float* vec = special_vec(a.g, a.queue, a.Q, D, a.special_col[st] - lo, src[st]);
         const float k = -a.scale * inv_pos * dtm;
@@ -1138,7 +1177,7 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   f.row_loss = row_loss;
   f.dP = dP;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
-  const size_t lds = ((size_t)((D + 3) & ~3) + 16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + 16;
+  const size_t lds = ((size_t)((D + 3) & ~3) + 16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + (size_t)4 * D * 4 + 16;
   if (lds > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish: too many special columns for one LDS image");
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)head_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1260,7 +1299,7 @@ static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const f
   sf.cand_col = cand_col;
   sf.sv_thr = sv ? thr : nullptr;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
-  const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + 16;
+  const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + (size_t)4 * D * 4 + 16;
   if (lds_f > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish_shard: too many special columns for one LDS image");
   if (lds_f > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)head_finish_shard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
