@@ -269,6 +269,14 @@ int vlsfr_embed_bwd(const float* demb, const float* emb, const float* inv_norm, 
  * dgrad operand wT bf16 [C][taps][rows] */
 int vlsfr_cast_weight(const float* w, void* w_bf16, void* wT_bf16, int32_t rows, int32_t taps, int32_t C,
                       int32_t Kp, void* stream);
+/* The same for n tensors in one launch (what the backbone executors use for their weight caches). */
+typedef struct vlsfr_cast_entry {
+  const float* w;      /* fp32 [rows][taps][C] */
+  void* w_bf16;        /* bf16 [rows][Kp], zero padded */
+  void* wT_bf16;       /* bf16 [C][taps][rows] or NULL */
+  int32_t rows, taps, C, Kp;
+} vlsfr_cast_entry;
+int vlsfr_cast_weights(const vlsfr_cast_entry* entries, int32_t n, void* stream);
 /* fp32 NCHW image [N,3,H,W] -> bf16 im2col rows [N*Ho*Wo][32] of the 3x3 pad-1 stem, stride 1
  * (iResNet, resnet_arcface.py:74) or 2 (MobileFaceNet, mobilefacenet_def.py:80); k=(r*3+s)*3+c */
 int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, int32_t stride,

@@ -304,17 +304,18 @@ size_t vlsfr_iresnet_scratch_bytes(const vlsfr_iresnet* n) { return n ? n->scrat
 int vlsfr_iresnet_prepare_weights(const vlsfr_iresnet* n, const float* const* params, void* wcache, void* st) {
   if (!n || !params || !wcache) return fail(VLSFR_EINVAL, "vlsfr_iresnet_prepare_weights: null argument");
   char* wc = (char*)wcache;
-  RUN(vlsfr_cast_weight(params[n->stem.p_w], wc + n->stem.off_wb, nullptr, 64, 1, 27, 32, st));
-  auto cast = [&](const Conv& c) {
-    return vlsfr_cast_weight(params[c.p_w], wc + c.off_wb, wc + c.off_wT, c.d.Cout, c.d.R * c.d.S, c.d.Cin,
-                             c.d.R * c.d.S * c.d.Cin, st);
+  std::vector<vlsfr_cast_entry> tab;
+  tab.push_back({params[n->stem.p_w], wc + n->stem.off_wb, nullptr, 64, 1, 27, 32});
+  auto add = [&](const Conv& c) {
+    tab.push_back({params[c.p_w], wc + c.off_wb, wc + c.off_wT, c.d.Cout, c.d.R * c.d.S, c.d.Cin, c.d.R * c.d.S * c.d.Cin});
   };
   for (const auto& b : n->blocks) {
-    RUN(cast(b.conv1));
-    RUN(cast(b.conv2));
-    if (b.has_ds) RUN(cast(b.convd));
+    add(b.conv1);
+    add(b.conv2);
+    if (b.has_ds) add(b.convd);
   }
-  return cast(n->fc);
+  add(n->fc);
+  return vlsfr_cast_weights(tab.data(), (int32_t)tab.size(), st);
 }
 
 int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params,

@@ -212,12 +212,13 @@ size_t vlsfr_mobilenet_scratch_bytes(const vlsfr_mobilenet* n) { return n ? n->s
 int vlsfr_mobilenet_prepare_weights(const vlsfr_mobilenet* n, const float* const* params, void* wcache, void* st) {
   if (!n || !params || !wcache) return fail(VLSFR_EINVAL, "vlsfr_mobilenet_prepare_weights: null argument");
   char* wc = (char*)wcache;
+  std::vector<vlsfr_cast_entry> tab;
   for (const auto& u : n->units) {
-    if (u.kind == STEM) RUN(vlsfr_cast_weight(params[u.p_w], wc + u.off_wb, nullptr, u.d.Cout, 1, 27, 32, st));
-    else if (u.kind == PW)
-      RUN(vlsfr_cast_weight(params[u.p_w], wc + u.off_wb, wc + u.off_wT, u.d.Cout, 1, u.d.Cin, u.d.Cin, st));
+    if (u.kind == STEM) tab.push_back({params[u.p_w], wc + u.off_wb, nullptr, u.d.Cout, 1, 27, 32});
+    else if (u.kind == PW) tab.push_back({params[u.p_w], wc + u.off_wb, wc + u.off_wT, u.d.Cout, 1, u.d.Cin, u.d.Cin});
   }
-  return vlsfr_cast_weight(params[n->l1_w], wc + n->l1_wb, wc + n->l1_wT, n->D, 1, 512, 512, st);
+  tab.push_back({params[n->l1_w], wc + n->l1_wb, wc + n->l1_wT, n->D, 1, 512, 512});
+  return vlsfr_cast_weights(tab.data(), (int32_t)tab.size(), st);
 }
 
 int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const float* const* params,
