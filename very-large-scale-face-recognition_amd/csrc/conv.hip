@@ -100,6 +100,10 @@ __device__ __forceinline__ int swz(int row) {
   else return row & 7;
 }
 
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
+                                              int r16, int h, int tid, float* red_lds);
+
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int MT = BM / 32;   // 16-row MFMA tiles per wave along output channels
@@ -232,60 +236,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
-  float cs[MT][4], cq[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int p = p0 + wn * (BN / 2) + j * 16 + r16;
-    if (p >= P) continue;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h;
-      if (m >= a.Mrows) continue;
-      if (a.out_f32) {
-        float* dst = (float*)a.y + (size_t)p * a.Mrows + m;
-        if (a.splitk > 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) atomicAdd(dst + e, acc[i][j][e]);
-        } else {
-          *(f32x4*)dst = acc[i][j];
-        }
-      } else {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (__bf16)acc[i][j][e];
-          const float f = (float)o[e];
-          cs[i][e] += f;
-          cq[i][e] += f * f;
-        }
-        *(bf16x4*)((u16*)a.y + (size_t)p * a.Mrows + m) = o;
-      }
-    }
-  }
-  if (a.stats) {   // fused BatchNorm statistics: reduce over the 16 pixel lanes, one atomic per channel and wave
-    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float s = cs[i][e], q = cq[i][e];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          s += __shfl_xor(s, o, 64);
-          q += __shfl_xor(q, o, 64);
-        }
-        const int m = m0 + wm * (BM / 2) + i * 16 + 4 * h + e;
-        if (r16 == 0 && m < a.Mrows) {
-          atomicAdd(dst + m, s);
-          atomicAdd(dst + a.Mrows + m, q);
-        }
-      }
-  }
+  // ---- epilogue shared with the LDS-DMA kernels (16-byte stores, DPP statistics); smem is free after the loop's last barrier
+  conv_epilogue<BM, BN, 2, 2, MT, NT, 4>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem);
 }
 
 // ------------------------------------------------------------------------------------------------
