@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Headline benchmark: faces/sec of the FFC training step (zero_grad -> forward -> backward ->
-SGD step) on N MI355X of one node.  Metric / config: BASELINE.json (`configs[1]` at N = 1:
-iResNet50 + 1M identities, FFC DCP, bf16 MFMA operands).
+SGD step) on N MI355X of one node.  Metric / config: BASELINE.json `metric` — iResNet100 +
+10 M identities (10 485 760 pool slots x 512, full residency: 41 GB of fp32 pool + a 10.7 GB bf16
+shadow fit one 288 GB GPU), FFC DCP, bf16 MFMA operands, batch_size 256 per GPU.  `configs[1]`
+(ir50 + 1M) is `--net ir50 --identities 1048576`.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -49,9 +51,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--net", default="ir50")
+    ap.add_argument("--net", default="ir100")
     ap.add_argument("--batch", type=int, default=256, help="--batch_size of the reference: rows of x and of y per GPU")
-    ap.add_argument("--identities", type=int, default=1 << 20)
+    ap.add_argument("--identities", type=int, default=10 << 20)
     ap.add_argument("--queue", type=int, default=0, help="pool slots (0 = one per identity, full residency)")
     ap.add_argument("--feat", type=int, default=512)
     ap.add_argument("--loss", default="Arc")
@@ -64,7 +66,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the "
                     "multi-process path on a 1-GPU box")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--c1-steps", type=int, default=5, help="timed steps of the C1 leg of the CPU baseline (0 = skip)")
     return ap.parse_args()
 
 
@@ -81,22 +84,15 @@ def synth_batch(rng, B, n_id, device):
     return imgs(), imgs(), torch.from_numpy(xl), torch.from_numpy(yl)
 
 
-def cpu_baseline(args):
-    """The oracle's CPU restatement (PyTorch CPU fp32, all host cores) of the same step on a bounded
-    sample: same backbone and feature size, reduced batch and pool so it finishes in ~10-30 s."""
+def _cpu_steps(o, B, n_id, steps, tag):
+    """Times `steps` oracle steps (zero_grad -> forward -> backward -> SGD-nesterov) after one warm-up step."""
     from oracle import ffc_ref
-    threads = host_threads()
-    torch.set_num_threads(threads)
-    B, Q = args.cpu_batch, 1 << 17
-    gen = torch.Generator().manual_seed(0)
-    o = ffc_ref.FFCRef(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, gen=gen)
-    o.lru.restore([(k, k) for k in range(4096)])          # a few thousand resident identities (O(n) oracle LRU)
     rng = np.random.default_rng(0)
     bufs = [None] * len(o.parameters())
     t_total, faces = 0.0, 0
-    for step in range(args.cpu_steps + 1):
-        x, y, xl, yl = synth_batch(rng, B, 4096, "cpu")
-        note("cpu baseline step %d" % step)
+    for step in range(steps + 1):
+        x, y, xl, yl = synth_batch(rng, B, n_id, "cpu")
+        note("cpu baseline %s step %d" % (tag, step))
         t0 = time.perf_counter()
         for p in o.parameters():
             p.grad = None
@@ -108,9 +104,33 @@ def cpu_baseline(args):
         if step > 0:                                      # first step = warm-up
             t_total += dt
             faces += 2 * B
-    return dict(value=faces / t_total, unit="faces/sec", cores=threads, kind="port",
-                sample="%s D=%d, pool 131072 slots, batch %d, %d timed steps, fp32 PyTorch-CPU oracle" %
-                       (args.net, args.feat, B, args.cpu_steps))
+    return faces / t_total
+
+
+def cpu_baseline(args):
+    """The oracle's CPU restatement (PyTorch CPU fp32, all host cores of this process's share) on two bounded samples:
+    (i) `value`: the GPU line's own backbone and feature size at a reduced batch and pool (the 10 M-slot pool and
+    batch 256 would take minutes per step on the host), (ii) `c1`: BASELINE.json configs[0] EXACTLY — MobileFaceNet,
+    D = 128, 1 000 identities / slots, batch_size 32, fp32 (the imported reference ran this at
+    ~42 faces/s on the build container's 8 vCPUs)."""
+    from oracle import ffc_ref
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    B, Q = args.cpu_batch, 1 << 17
+    gen = torch.Generator().manual_seed(0)
+    o = ffc_ref.FFCRef(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, gen=gen)
+    o.lru.restore([(k, k) for k in range(4096)])          # a few thousand resident identities (O(n) oracle LRU)
+    value = _cpu_steps(o, B, 4096, args.cpu_steps, args.net)
+    out = dict(value=value, unit="faces/sec", cores=threads, kind="port",
+               sample="%s D=%d, pool 131072 slots, batch_size %d, %d timed steps after 1 warm-up, fp32 PyTorch-CPU oracle" %
+                      (args.net, args.feat, B, args.cpu_steps))
+    if args.c1_steps > 0:
+        gen = torch.Generator().manual_seed(0)
+        o1 = ffc_ref.FFCRef("mobile", 128, 1000, 32.0, "Arc", 0.5, 0.99, gen=gen)
+        out["c1"] = dict(value=_cpu_steps(o1, 32, 1000, args.c1_steps, "C1"), unit="faces/sec", cores=threads,
+                         sample="BASELINE configs[0] exactly: MobileFaceNet D=128, 1000 identities, pool 1000 slots, "
+                                "batch_size 32, Arc, fp32, %d timed steps after 1 warm-up" % args.c1_steps)
+    return out
 
 
 def main():
@@ -145,19 +165,24 @@ def main():
 
     Q = args.queue or args.identities
     torch.manual_seed(1234)                                   # identical initial weights on every rank
-    model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99).cuda()
+    sharded = world > 1 and args.pool == "sharded" and Q % world == 0
+    # the pool is drawn straight into HBM in chunks (ffc.build_pool: same normalize(rand) semantics as
+    # ffc.py:29-30); under the identity-sharded pool every rank builds only its own slots
+    model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, pool_device=dev,
+                pool_shard=(rank, world) if sharded else None).cuda()
     if args.serial:
         model.__dict__['concurrent_streams'] = False
         model.probe_net.concurrent_backward = False
     n_res = min(Q, args.identities)
-    model.lru.restore(list(zip(range(n_res), range(n_res))))  # steady state: the pool is full (lru.py:113)
+    ar = np.arange(n_res)
+    model.lru.restore_arrays(ar.astype(np.int64), ar.astype(np.int32))   # steady state: the pool is full (lru.py:113)
+    note("pool %d slots on device (%.1f GB), LRU restored" % (Q, model.queue.numel() * 4 / 1e9))
     cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
                milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])     # config/optim_config
     opt, sched = get_optim_scheduler([p for p in model.parameters() if p.requires_grad], cfg)
     sched.update(0, 0.0)
     step_model = model
     if world > 1:
-        sharded = args.pool == "sharded" and Q % world == 0
         step_model = ShardedFFC(model, dist) if sharded else DataParallelFFC(model, dist)
     rng = np.random.default_rng(1234 + rank)
     B = args.batch
@@ -270,8 +295,10 @@ def main():
         pass
     faces = world * 2 * B * args.steps
     out = {
-        "metric": "faces/sec (whole node) at %s-identity FFC, %s" % (
-            "%dM" % (args.identities >> 20) if args.identities >= (1 << 20) else str(args.identities), args.net),
+        "metric": ("faces/sec (whole node) at 10M-identity FFC, iResNet100, 1/2/4/8 MI355X"
+                   if (args.net, args.identities) == ("ir100", 10 << 20) else
+                   "faces/sec (whole node) at %s-identity FFC, %s" % (
+                       "%dM" % (args.identities >> 20) if args.identities >= (1 << 20) else str(args.identities), args.net)),
         "value": round(faces / dt, 2), "unit": "faces/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

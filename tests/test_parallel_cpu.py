@@ -41,6 +41,9 @@ def _worker(rank, world, port, out):
             def buffers(self):
                 return []
 
+            def named_buffers(self):
+                return []
+
         dp = DataParallelFFC(Stub(), dist)
         Q, D, B = 64, 16, 6
         rng = np.random.default_rng(100 + rank)

@@ -1,0 +1,377 @@
+// head_sweep16: the Dynamic-Class-Pool sweep over the bf16 SHADOW of queue[0] (D = 512) for gfx950.
+//
+// Same math as head_sweep_kernel (head.hip; reference ffc.py:195-201 / 248-253 + the softmax of
+// F.cross_entropy, ffc.py:83/104/127, and its backward): S^T = W_tile . P^T on MFMA, online softmax in
+// base 2 with deferred rescale, O += P~ . W_tile with the SAME LDS image read back transposed.  What
+// is different is how the bytes and the registers are spent (the fp32-streaming
+// kernel read 1 KiB of LDS per MFMA and converted on the VALU — bound by neither roof):
+//   * the pool is streamed as bf16 (half the HBM bytes; the fp32 master in queue[] stays the source of
+//     truth for the special columns, the precise mode and the checkpoint) straight into a 4-stage LDS
+//     ring by LDS-DMA: one pool row = 1024 B = exactly one `buffer_load_dwordx4 ... lds` wave-instruction,
+//     so rows keep the 32-byte pad that makes both the ds_read_b128 row reads and the
+//     ds_read_b64_tr_b16 block reads bank-conflict free; rows past the chunk end are out of range for
+//     the buffer descriptor and arrive as zeros.  Two tiles (66 KB) are in flight per CU behind a
+//     counted s_waitcnt vmcnt, one raw s_barrier per tile.
+//   * RB = 2: a wave owns 32 probe rows (two 16-row MFMA blocks) with P in registers (128 VGPRs) and
+//     O in 256 accumulator registers, one wave per SIMD — every W fragment read from LDS feeds two
+//     MFMAs in both products: 0.5 KiB of LDS per MFMA, the LDS pipe is half busy at the MFMA rate.
+//     RB = 1 (batch <= 64): 16 rows per wave; that case is HBM-bound.
+//   * all LDS reads of the loop are inline asm behind counted lgkmcnt waits (the compiler would put a
+//     vmcnt(0) in front of any LDS read it can see while a DMA is pending and drain the ring).
+//   * hard-negative candidates (rows with label -1, ffc.py:86-90): a lane keeps only the admission
+//     threshold of its private top-10 list in a register; the list itself lives in the partial-result
+//     buffer (L2-resident) and is touched only on the rare admission.
+#include "hip_common.h"
+#include "head_sweep16.h"
+
+#include <utility>
+
+using namespace vlsfr;
+
+namespace {
+
+constexpr int TQ = SW16_TQ;
+constexpr int DP = SW16_D;
+constexpr int KTOP = SW16_KTOP;
+constexpr int ROWB = DP * 2 + 32;     // LDS bytes per pool row (32-byte pad, see head.hip swz_off)
+constexpr int TILE_B = TQ * ROWB;     // 33 792
+constexpr int NS = 4;                 // ring stages
+constexpr int KS = DP / 32;           // k-steps of the first product
+constexpr int NB = DP / 16;           // 16-column blocks of the second product
+constexpr int PF1 = 4;                // k-steps of fragment reads in flight (first product)
+constexpr int PF2 = 4;                // column blocks of transposed reads in flight (second product)
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float DEFER_THR = 12.0f;    // deferred-rescale threshold in log2 units
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_r128(uint32_t addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ short4v lds_rtr(uint32_t addr) {
+  short4v v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
+  uint32_t v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <int RB, bool TOPK, bool SV>
+__global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* bits = (uint32_t*)(smem + NS * TILE_B);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15;
+  const int h = lane >> 4;
+  // XCD-aware block order (as head_sweep_kernel): the row blocks of one column chunk get ids 8 apart inside
+  // one group of 8 * n_rowblk consecutive ids, so they run at the same time on one XCD and the chunk is
+  // fetched from HBM once.
+  const int nrb = a.n_rowblk;
+  const int within = blockIdx.x % (8 * nrb);
+  const int chunk = (blockIdx.x / (8 * nrb)) * 8 + (within & 7);
+  const int rowblk = within >> 3;
+  const int64_t c0 = (int64_t)chunk * a.chunk_cols;
+  const int64_t c1 = (c0 + a.chunk_cols < a.Q) ? c0 + a.chunk_cols : a.Q;
+  const int ncols = c1 > c0 ? (int)(c1 - c0) : 0;
+  const int ntiles = (ncols + TQ - 1) / TQ;
+  const int row_base = rowblk * (64 * RB) + wave * (16 * RB);
+  const bool wave_active = row_base < a.B;     // wave-uniform
+
+  // ---- special-column bitmap of this chunk: one 32-bit word per tile (plain LDS ops: no DMA is pending yet)
+  const int nwords = a.chunk_cols / TQ;
+  for (int i = tid; i < nwords; i += 256) bits[i] = 0u;
+  __syncthreads();
+  for (int i = tid; i < a.n_special; i += 256) {
+    const int64_t c = (int64_t)a.special_col[i] - a.slot_lo;   // special columns carry global slot ids
+    if (c >= c0 && c < c1) atomicOr(&bits[(c - c0) >> 5], 1u << ((c - c0) & 31));
+  }
+  __syncthreads();
+
+  // ---- P fragments (B operand of S^T = W . P^T): lane holds P[row 16 rb + r16][32 ks + 8 h + j]
+  bf16x8 pf[RB][KS];
+  float sv_thr[RB];
+  bool is_out[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int prow = row_base + 16 * rb + r16;
+    const bool ok = wave_active && prow < a.B;
+    const f32x4* src = (const f32x4*)(a.p + (size_t)(ok ? prow : 0) * DP + h * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f32x4 v0 = src[ks * 8], v1 = src[ks * 8 + 1];
+      if (!ok) {
+        v0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        v1 = v0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[rb][ks][j] = (__bf16)v0[j];
+        pf[rb][ks][4 + j] = (__bf16)v1[j];
+      }
+    }
+    sv_thr[rb] = (SV && ok) ? a.sv_thr[prow] : 0.f;
+    is_out[rb] = TOPK && ok && a.pool_label[prow] < 0;
+  }
+
+  // ---- accumulators and softmax state
+  f32x4 oacc[RB][NB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) oacc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_ref[RB], l_part[RB], tk_thr[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    m_ref[rb] = NEG_BIG;   // reference exponent of row r16 (log2 units), identical in the 4 h-lanes
+    l_part[rb] = 0.f;      // this lane's share of sum 2^(s - m_ref)
+    tk_thr[rb] = NEG_BIG;  // admission threshold of this lane's candidate list
+  }
+  // candidate lists of this lane: [chunk][row][h][KTOP] in the partial buffers
+  auto list_base = [&](int rb) -> size_t {
+    return (((size_t)chunk * a.Bp + row_base + 16 * rb + r16) * 4 + h) * KTOP;
+  };
+  if (TOPK && wave_active) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const size_t lb = list_base(rb);
+#pragma unroll
+      for (int k = 0; k < KTOP; ++k) {
+        a.topk_val[lb + k] = NEG_BIG;
+        a.topk_idx[lb + k] = -1;
+      }
+    }
+  }
+
+  // ---- LDS-DMA: wave w fetches rows 8w .. 8w + 7 of a tile, one 1-KiB instruction per pool row
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.w16 + (size_t)(ncols > 0 ? c0 : 0) * DP), 0, ncols * (DP * 2), 0x00020000);
+  const int voff = lane * 16;
+  auto issue = [&](int t) {
+    char* st = smem + (t % NS) * TILE_B + wave * 8 * ROWB;
+    const int soff = (t * TQ + wave * 8) * (DP * 2);   // rows past the chunk end: out of range -> zeros
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(st + i * ROWB), 16, voff, soff + i * (DP * 2), 0, 0);
+  };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const uint32_t bits0 = lds0 + NS * TILE_B;
+  const uint32_t off1 = (uint32_t)(r16 * ROWB + h * 16);                      // row reads: row r16 (+16 jb), chunk 4 ks + h
+  const uint32_t off2 = (uint32_t)((4 * h + (r16 >> 2)) * ROWB + (r16 & 3) * 8);   // transposed reads: block row 4h + q, 4-column group p
+
+#pragma unroll
+  for (int t = 0; t < NS - 1; ++t) issue(t);
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 8) : "memory");   // this wave's rows of tile t have landed
+    __builtin_amdgcn_s_barrier();                                           // everybody's; and tile t - 1 is no longer read
+    issue(t + NS - 1);                                                      // into the slot of tile t - 1
+    if (wave_active) {
+      const uint32_t sb = lds0 + (uint32_t)((t % NS) * TILE_B);
+      const uint32_t a1 = sb + off1, a2 = sb + off2;
+      const uint32_t word = lds_r32(bits0 + 4u * (uint32_t)t);
+      // ================= first product: S^T[j][i], j = 2 blocks of 16 pool columns, i = RB blocks of 16 probe rows
+      f32x4 sacc[2][RB];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) sacc[jb][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      bf16x8 wa[PF1 + 1][2];
+      static_for<PF1>([&](auto I) {
+        constexpr int ks = decltype(I)::value;
+        wa[ks][0] = lds_r128<ks * 64>(a1);
+        wa[ks][1] = lds_r128<16 * ROWB + ks * 64>(a1);
+      });
+      static_for<KS>([&](auto I) {
+        constexpr int ks = decltype(I)::value;
+        if constexpr (ks + PF1 < KS) {
+          constexpr int kn = ks + PF1;
+          wa[kn % (PF1 + 1)][0] = lds_r128<kn * 64>(a1);
+          wa[kn % (PF1 + 1)][1] = lds_r128<16 * ROWB + kn * 64>(a1);
+        }
+        constexpr int later = (KS - 1 - ks) < PF1 ? (KS - 1 - ks) : PF1;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * later) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) sacc[jb][rb] = mfma16(wa[ks % (PF1 + 1)][jb], pf[rb][ks], sacc[jb][rb]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // transposed reads of the first column blocks of the second product fly under the softmax
+      short4v tb[PF2 + 1][2];
+      static_for<PF2>([&](auto I) {
+        constexpr int nb = decltype(I)::value;
+        tb[nb][0] = lds_rtr<nb * 32>(a2);
+        tb[nb][1] = lds_rtr<16 * ROWB + nb * 32>(a2);
+      });
+      // ================= softmax: lane (r16, h) holds cos(p row 16 rb + r16, pool column tile + 16 jb + 4 h + e)
+      const int64_t ct = c0 + (int64_t)t * TQ;
+      const bool plain = (word == 0u) && (ct + TQ <= c1) && !TOPK;   // wave-uniform: no masked column in this tile
+      bf16x8 pa[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        float s[8], av[8];
+        bool valid[8];
+        float tmax = NEG_BIG;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int jb = q >> 2, e = q & 3;
+          float c = sacc[jb][rb][e];
+          bool ok = true;
+          if (!plain) {
+            const int jl = jb * 16 + 4 * h + e;
+            ok = (ct + jl < c1) && !((word >> jl) & 1u);
+            if (TOPK) {
+              if (ok && is_out[rb] && c > tk_thr[rb]) {   // rare after the first tiles
+                float cv = c;
+                int ci = (int)(ct + jl);
+                const size_t lb = list_base(rb);
+#pragma unroll
+                for (int k = 0; k < KTOP; ++k) {
+                  const float tv = a.topk_val[lb + k];
+                  const int ti = a.topk_idx[lb + k];
+                  const bool gt = cv > tv;
+                  a.topk_val[lb + k] = gt ? cv : tv;
+                  a.topk_idx[lb + k] = gt ? ci : ti;
+                  cv = gt ? tv : cv;
+                  ci = gt ? ti : ci;
+                }
+                tk_thr[rb] = a.topk_val[lb + KTOP - 1];
+              }
+            }
+          }
+          float fac = 1.f;
+          if (SV) {
+            if (c > sv_thr[rb]) {                                   // ffc.py:122-125
+              c = a.sv_t * c + a.sv_t - 1.f;
+              fac = a.sv_t;
+            }
+          }
+          av[q] = fac;
+          valid[q] = ok;
+          s[q] = ok ? c * a.qscale : NEG_BIG;
+          tmax = fmaxf(tmax, s[q]);
+        }
+        tmax = lane_step_max<16>(tmax);
+        tmax = lane_step_max<32>(tmax);
+        // deferred rescale: move the reference exponent only when the row maximum outgrows it
+        const bool grow = tmax > m_ref[rb] + DEFER_THR;
+        if (__any(grow)) {
+          const float m_new = grow ? tmax : m_ref[rb];
+          const float alpha = grow ? __builtin_amdgcn_exp2f(m_ref[rb] - m_new) : 1.f;
+          m_ref[rb] = m_new;
+          l_part[rb] *= alpha;
+          float al[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) al[e] = __shfl(alpha, 4 * h + e, 64);   // O rows are 4h + e
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) oacc[rb][nb][e] *= al[e];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float pe = __builtin_amdgcn_exp2f(s[q] - m_ref[rb]);
+          if (!plain) pe = valid[q] ? pe : 0.f;
+          l_part[rb] += pe;
+          pa[rb][q] = (__bf16)(SV ? pe * av[q] : pe);
+        }
+      }
+      // ================= second product: O[i][d] += sum_j P~[i][j] W[j][d]
+      // k index of the MFMA: element q of lane group h  <->  tile row 16 (q>>2) + 4h + (q&3), which is how pa is laid
+      // out; B comes from two transposed 4x16 block reads (rows 4h + .., and + 16).
+      static_for<NB>([&](auto I) {
+        constexpr int nb = decltype(I)::value;
+        if constexpr (nb + PF2 < NB) {
+          constexpr int nn = nb + PF2;
+          tb[nn % (PF2 + 1)][0] = lds_rtr<nn * 32>(a2);
+          tb[nn % (PF2 + 1)][1] = lds_rtr<16 * ROWB + nn * 32>(a2);
+        }
+        constexpr int later = (NB - 1 - nb) < PF2 ? (NB - 1 - nb) : PF2;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * later) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const short4v b0 = tb[nb % (PF2 + 1)][0], b1 = tb[nb % (PF2 + 1)][1];
+        const short __attribute__((ext_vector_type(8))) bs = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const bf16x8 wb = __builtin_bit_cast(bf16x8, bs);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) oacc[rb][nb] = mfma16(pa[rb], wb, oacc[rb][nb]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-fill DMAs issued past the last tile
+
+  // ---- write partials
+  if (wave_active) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float l_row = l_part[rb];
+      l_row = lane_step_sum<16>(l_row);
+      l_row = lane_step_sum<32>(l_row);
+      const int prow = row_base + 16 * rb + r16;
+      const size_t pr = (size_t)chunk * a.Bp + prow;
+      if (h == 0) {
+        a.part_m[pr] = m_ref[rb];
+        a.part_l[pr] = l_row;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const size_t orow = (size_t)chunk * a.Bp + row_base + 16 * rb + 4 * h + e;
+          a.part_o[orow * DP + nb * 16 + r16] = oacc[rb][nb][e];
+        }
+    }
+  }
+}
+
+template <int RB>
+int launch_rb(const Sweep16Args& a, bool topk, bool sv, hipStream_t st) {
+  const size_t lds = sweep16_lds_bytes(a.chunk_cols);
+  const dim3 grid(a.n_chunks * a.n_rowblk);
+#define VLSFR_SWEEP16(T, S)                                                                                      \
+  do {                                                                                                          \
+    auto kern = head_sweep16_kernel<RB, T, S>;                                                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return hip_fail(e, "head_sweep16: hipFuncSetAttribute");                               \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);                                                      \
+  } while (0)
+  if (topk && sv) VLSFR_SWEEP16(true, true);
+  else if (topk) VLSFR_SWEEP16(true, false);
+  else if (sv) VLSFR_SWEEP16(false, true);
+  else VLSFR_SWEEP16(false, false);
+#undef VLSFR_SWEEP16
+  VLSFR_HIP_CHECK_LAUNCH("head_sweep16 launch");
+  return VLSFR_OK;
+}
+
+}  // namespace
+
+namespace vlsfr {
+
+size_t sweep16_lds_bytes(int chunk_cols) { return (size_t)NS * TILE_B + (size_t)(chunk_cols / TQ) * 4 + 16; }
+
+int launch_sweep16(const Sweep16Args& a, int RB, bool topk, bool sv, hipStream_t st) {
+  if (a.chunk_cols % TQ != 0 || a.chunk_cols / TQ > SW16_MAX_TILES || a.n_chunks % 8 != 0 || a.Bp != a.n_rowblk * 64 * RB)
+    return fail(VLSFR_EINVAL, "head_sweep16: inconsistent plan (chunk_cols %d, n_chunks %d, Bp %d)", a.chunk_cols, a.n_chunks, a.Bp);
+  if (RB == 1) return launch_rb<1>(a, topk, sv, st);
+  if (RB == 2) return launch_rb<2>(a, topk, sv, st);
+  return fail(VLSFR_EINVAL, "head_sweep16: RB must be 1 or 2");
+}
+
+}  // namespace vlsfr

@@ -1,0 +1,41 @@
+// Interface between head.hip (plan, special columns, finish) and head16.hip (the bf16-shadow sweep).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vlsfr {
+
+constexpr int SW16_D = 512;        // feature size the fast sweep is built for (one pool row = one 1-KiB LDS-DMA)
+constexpr int SW16_TQ = 32;        // pool columns per tile
+constexpr int SW16_KTOP = 10;      // max hard_neg (ffc.py:48)
+constexpr int SW16_MAX_TILES = 4096;   // tiles per column chunk (special-column bitmap: one 32-bit word per tile)
+
+struct Sweep16Args {
+  const float* p;            // [B, 512] fp32 probe embeddings
+  const uint16_t* w16;       // bf16 shadow of queue[0]: [Q][512]
+  int64_t Q;
+  int32_t B;
+  int32_t chunk_cols;        // multiple of SW16_TQ, <= SW16_MAX_TILES * SW16_TQ
+  int32_t n_chunks;          // multiple of 8
+  const int32_t* special_col;
+  int32_t n_special;
+  const int32_t* pool_label; // [B]; rows with -1 collect hard-negative candidates
+  float qscale;              // scale * log2(e)
+  const float* sv_thr;       // SV: per-row hard-example threshold (cos units) or nullptr
+  float sv_t;                // SV: mask_svfc (1.2)
+  float* part_m;             // [n_chunks, Bp]
+  float* part_l;             // [n_chunks, Bp]
+  float* part_o;             // [n_chunks, Bp, 512]
+  float* topk_val;           // [n_chunks, Bp, 4, KTOP]
+  int32_t* topk_idx;
+  int32_t Bp;                // n_rowblk * 64 * RB
+  int32_t n_rowblk;
+  int32_t slot_lo;
+};
+
+// RB = 16-row blocks per wave: 1 (64 probe rows per workgroup; B <= 64, HBM-bound) or 2 (128 rows per
+// workgroup; MFMA-bound).  grid = n_chunks * n_rowblk workgroups of 256 threads.
+int launch_sweep16(const Sweep16Args& a, int RB, bool topk, bool sv, hipStream_t st);
+size_t sweep16_lds_bytes(int chunk_cols);
+
+}  // namespace vlsfr

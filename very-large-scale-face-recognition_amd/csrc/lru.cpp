@@ -251,11 +251,11 @@ int vlsfr_lru_restore(vlsfr_lru* h, const int64_t* keys, const int32_t* slots, i
   if (!h || (n > 0 && (!keys || !slots))) return vlsfr::fail(VLSFR_EINVAL, "vlsfr_lru_restore: null argument");
   if (n > h->capacity) return vlsfr::fail(VLSFR_ESTATE, "vlsfr_lru_restore: more entries than capacity");
   if (h->cur_idx != 0) return vlsfr::fail(VLSFR_ESTATE, "vlsfr_lru_restore: LRU is not empty (cur_idx != 0)");
-  // validate before mutating: distinct keys, slots in range and distinct (a slot is a node here)
+  // validate before touching the list: slots in range and distinct (a slot is a node here); keys are checked
+  // for duplicates while they go into the (empty: cur_idx == 0) key table, which is wiped again on failure —
+  // no second hash map, so a 10 M-entry restore costs one pass
   {
-    std::vector<uint8_t> seen((size_t)h->capacity, 0);
-    std::unordered_map<int64_t, int> kseen;
-    kseen.reserve((size_t)n * 2);
+    std::vector<uint8_t> seen((size_t)(n > 0 ? n : 1), 0);
     for (int64_t i = 0; i < n; ++i) {
       // a state_dict of a live LRU always holds exactly the slots 0..n-1 (handed out in order,
       // never freed); anything else would let a later Add collide with a restored slot
@@ -263,14 +263,20 @@ int vlsfr_lru_restore(vlsfr_lru* h, const int64_t* keys, const int32_t* slots, i
         return vlsfr::fail(VLSFR_EINVAL, "vlsfr_lru_restore: slots must be a permutation of 0..n-1");
       if (seen[slots[i]]) return vlsfr::fail(VLSFR_EINVAL, "vlsfr_lru_restore: duplicate slot");
       seen[slots[i]] = 1;
-      if (!kseen.emplace(keys[i], 1).second || h->find(keys[i]) >= 0)
+    }
+    if (h->live != 0) return vlsfr::fail(VLSFR_ESTATE, "vlsfr_lru_restore: LRU is not empty");
+    for (int64_t i = 0; i < n; ++i) {
+      if (h->find(keys[i]) >= 0) {
+        std::fill(h->table.begin(), h->table.end(), -1);
+        h->live = 0;
         return vlsfr::fail(VLSFR_ESTATE, "vlsfr_lru_restore: duplicate key");
+      }
+      h->insert(keys[i], slots[i]);
     }
   }
   int32_t cur = h->head;
   for (int64_t i = 0; i < n; ++i) {
     int32_t s = slots[i];
-    h->insert(keys[i], s);
     h->next[cur] = s;
     h->prev[s] = cur;
     cur = s;

@@ -18,15 +18,62 @@ from .head import DcpHead, QueuePositionView
 from .model import create_net
 
 
+POOL_CHUNK = 1 << 16          # slots per generator chunk of a device-built pool
+POOL_HOST_LIMIT = 256 << 20   # pools up to this many bytes are built exactly as the reference does (host, global RNG)
+
+
+def build_pool(queue_size, feat_dim, device=None, shard=None, seed=None):
+    """``F.normalize(torch.rand(2, Q, D), dim=2)`` (ffc.py:29-30).
+
+    Small pools (and ``device='cpu'``) use that very expression, so ``torch.manual_seed`` gives the
+    reference's pool.  Large pools (10 M identities: 41 GB; 100 M: 410 GB — SURVEY a1) are never
+    materialised on the host: the same distribution is drawn straight into HBM in chunks of POOL_CHUNK
+    slots, chunk c from its own generator seeded ``seed + c`` (``seed`` is one draw from the global
+    CPU generator, so ``torch.manual_seed`` still fixes the pool and every rank that seeds alike agrees).
+    ``shard = (rank, world)`` builds only slots [rank * Q / world, (rank + 1) * Q / world) — bit-identical
+    to that slice of the full pool, which is what lets an identity-sharded run (parallel.ShardedFFC)
+    start from the single-GPU run's pool without any rank ever holding all of it."""
+    lo, n = 0, queue_size
+    if shard is not None:
+        rank, world = shard
+        if queue_size % world:
+            raise ValueError("queue_size must be divisible by the number of ranks for a sharded pool")
+        n = queue_size // world
+        lo = rank * n
+    nbytes = 2 * n * feat_dim * 4
+    if device is None:
+        device = 'cuda' if (torch.cuda.is_available() and nbytes > POOL_HOST_LIMIT) else 'cpu'
+    device = torch.device(device)
+    if device.type == 'cpu' and shard is None and seed is None:
+        return F.normalize(torch.rand(2, queue_size, feat_dim), dim=2)
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    gen = torch.Generator(device=device)
+    out = torch.empty(2, n, feat_dim, dtype=torch.float32, device=device)
+    c = lo // POOL_CHUNK
+    while c * POOL_CHUNK < lo + n:
+        a, b = c * POOL_CHUNK, min((c + 1) * POOL_CHUNK, queue_size)
+        gen.manual_seed(seed + c)
+        blk = F.normalize(torch.rand(2, b - a, feat_dim, generator=gen, device=device), dim=2)
+        s0, s1 = max(a, lo), min(b, lo + n)
+        out[:, s0 - lo:s1 - lo] = blk[:, s0 - a:s1 - a]
+        c += 1
+    return out
+
+
 class FFC(Module):
     def __init__(self, net_type, feat_dim, queue_size=7409, scale=32.0, loss_type='AM', margin=0.4, momentum=0.99,
-                 neg_margin=0.25, pretrained_model_path=None, num_class=None, precise_head=False):
+                 neg_margin=0.25, pretrained_model_path=None, num_class=None, precise_head=False,
+                 pool_device=None, pool_shard=None):
         super(FFC, self).__init__()
         assert loss_type in ('AM', 'Arc', 'SV')                       # ffc.py:17
         self.device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.probe_net = create_net(net_type, feat_dim=feat_dim, fp16=True)      # ffc.py:22-23
         self.gallery_net = create_net(net_type, feat_dim=feat_dim, fp16=True)
-        self.register_buffer('queue', F.normalize(torch.rand(2, queue_size, feat_dim), dim=2))   # ffc.py:29-30
+        self.pool_shard = pool_shard
+        self.register_buffer('queue', build_pool(queue_size, feat_dim, pool_device, pool_shard))   # ffc.py:29-30
         self.queue_size = queue_size
         self.feat_dim = feat_dim
         self.scale = scale
@@ -62,6 +109,9 @@ class FFC(Module):
         q = self.queue
         if not q.is_cuda:
             raise _lib.VlsfrError("FFC.forward: move the module to the GPU first (.cuda()); there is no CPU path")
+        if q.shape[1] != self.queue_size:
+            raise _lib.VlsfrError("this FFC holds pool slots of shard %r only: drive it through parallel.ShardedFFC" %
+                                  (self.pool_shard,))
         if self._head is None or self._head_qptr != q.data_ptr():
             if not q.is_contiguous():
                 self.queue = q = q.contiguous()
@@ -69,7 +119,11 @@ class FFC(Module):
             head = DcpHead(q, self.scale, self.margin, self.loss_type, precise=self.precise_head)
             head.lru, head.qp = old.lru, old.qp          # keep the allocator state across re-binds
             self._head, self._head_qptr = head, q.data_ptr()
-        return self._head
+        head = self._head
+        # the reference reads these attributes on every add_margin call (ffc.py:60-138): follow later changes
+        head.scale, head.margin, head.loss_type, head.precise = float(self.scale), float(self.margin), self.loss_type, bool(self.precise_head)
+        head.hard_neg = int(self.hard_neg)
+        return head
 
     @torch.no_grad()
     def _momentum_update_gallery(self):                               # ffc.py:139-145

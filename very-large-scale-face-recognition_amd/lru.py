@@ -155,6 +155,24 @@ class LRU(object):
             raise AssertionError(self._L.vlsfr_last_error().decode())
         _lib.check(rc, "vlsfr_lru_restore")
 
+    def restore_arrays(self, keys, slots):
+        """`restore` for bulk state: int64 keys and int32 slots as arrays, MRU -> LRU, same contract
+        (empty LRU, distinct keys, slots a permutation of 0..n-1).  A 10 M-identity pool restores in about a
+        second this way; the list-of-tuples form of the reference API needs 10 M Python objects."""
+        keys = np.ascontiguousarray(np.asarray(keys, dtype=np.int64))
+        slots = np.ascontiguousarray(np.asarray(slots, dtype=np.int32))
+        assert keys.ndim == 1 and keys.shape == slots.shape
+        assert keys.shape[0] <= self.capacity
+        assert self.cur_idx == 0
+        rc = self._L.vlsfr_lru_restore(self._h, keys.ctypes.data, slots.ctypes.data, keys.shape[0])
+        if rc == -2:
+            raise AssertionError(self._L.vlsfr_last_error().decode())
+        _lib.check(rc, "vlsfr_lru_restore")
+
+    def state_arrays(self):
+        """`state_dict` as (int64 keys, int32 slots) arrays, MRU -> LRU."""
+        return self._state_arrays()
+
     # lru.py:132-141
     def clear(self):
         _lib.check(self._L.vlsfr_lru_clear(self._h), "vlsfr_lru_clear")

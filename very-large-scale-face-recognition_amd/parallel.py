@@ -31,7 +31,8 @@ class DataParallelFFC(object):
         self.rccl = dist.get_backend() == "nccl"   # "nccl" IS RCCL on ROCm; gloo only in the 1-GPU rehearsal
         self._flat = None
         # identical starting point on every rank
-        for t in list(model.parameters()) + list(model.buffers()):
+        pre_sharded = getattr(model, 'pool_shard', None) is not None   # every rank built its own slots (ffc.build_pool)
+        for t in list(model.parameters()) + [b for n, b in model.named_buffers() if not (pre_sharded and n == 'queue')]:
             if self.rccl:
                 dist.broadcast(t.data, src=0)
             else:
@@ -134,7 +135,13 @@ class ShardedFFC(DataParallelFFC):
         if Q % self.world:
             raise ValueError("queue_size must be divisible by the number of ranks for the sharded pool")
         Qs = Q // self.world
-        shard = model.queue[:, self.rank * Qs:(self.rank + 1) * Qs].contiguous()
+        if getattr(model, 'pool_shard', None) is not None:
+            if tuple(model.pool_shard) != (self.rank, self.world) or model.queue.shape[1] != Qs:
+                raise ValueError("FFC was built with pool_shard=%r, this process is rank %d of %d" %
+                                 (model.pool_shard, self.rank, self.world))
+            shard = model.queue                  # built shard-local: no rank ever held the whole pool
+        else:
+            shard = model.queue[:, self.rank * Qs:(self.rank + 1) * Qs].contiguous()
         state = model._state()
         model.queue = shard                      # releases the full replica
         model._head = None
