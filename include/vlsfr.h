@@ -117,7 +117,12 @@ int vlsfr_dcp_undo(vlsfr_lru* h, uint8_t* qp, const int32_t* undo_slot, const ui
  * [slot_lo, slot_lo + Q)) writes to slots of other ranks are skipped */
 int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g /*[n, D]*/,
                        const int32_t* rows /*[n] dev*/, const int32_t* cols /*[n] dev*/, int32_t n,
-                       int32_t slot_lo, void* stream);
+                       int32_t slot_lo, void* shadow_bf16 /* [Q, D] bf16 mirror of queue[0], or NULL */, void* stream);
+/* bf16 shadow of queue[0] ([Q, D], round-to-nearest-even), the operand the head sweep streams when
+ * vlsfr_head_cfg.pool_bf16 is set: half the HBM bytes of the fp32 pool and no in-kernel conversion.  The fp32
+ * master stays the source of truth (special columns, precise mode, checkpoint); the caller rebuilds the shadow
+ * whenever it changes queue[0] by other means than vlsfr_pool_scatter (load_state_dict, copy_). */
+int vlsfr_pool_shadow_build(const float* queue0 /*[Q, D]*/, void* shadow_bf16, int64_t Q, int32_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Fused DCP head (device): loss and dL/dp of one FFC pass in one sweep over queue[0].
@@ -145,8 +150,16 @@ typedef struct vlsfr_head_cfg {
   int32_t n_rows_total;   /* 0 or B: single process.  > B: this call holds B probe rows of a batch of
                              n_rows_total rows spread over ranks (g, the special table, n_pos and the
                              loss normalisers refer to the whole batch; pool_label to these B rows) */
+  const void* pool_bf16;  /* NULL, or the bf16 shadow [Q, D] of queue[0] (vlsfr_pool_shadow_build).  With D = 512,
+                             precise = 0 and scale <= 64 the sweep then runs the LDS-DMA kernel of csrc/head16.hip
+                             on it; it relies on what the reference's pool guarantees — every row of queue[] is an
+                             F.normalize output (ffc.py:30,182), so |cos| <= |p| — to fix the softmax reference
+                             exponent per row up front instead of tracking a running maximum.  The workspace size
+                             depends on this field: query with the cfg the call will use. */
 } vlsfr_head_cfg;
 
+/* sizeof(vlsfr_head_cfg) as this library was compiled: bindings assert their mirror of the struct against it */
+size_t vlsfr_head_cfg_size(void);
 size_t vlsfr_head_workspace_bytes(const vlsfr_head_cfg* cfg);
 /* Identity-sharded pool (the class matrix split by slot range over the ranks of a node): this rank's
  * partial softmax state of one pass for ALL B rows of the (all-gathered) batch over its own slots —

@@ -65,10 +65,12 @@ def oracle_pass(queue, lru, qp, p, g, pl, gl, trans, loss_type, scale, margin, h
 
 
 @pytest.mark.parametrize("loss_type,margin", [("Arc", 0.5), ("AM", 0.4), ("SV", 0.35)])
-@pytest.mark.parametrize("Q,D,B,n_id", [(5000, 128, 64, 4000), (3001, 512, 40, 9000), (70000, 512, 96, 50000)])
+@pytest.mark.parametrize("Q,D,B,n_id", [(5000, 128, 64, 4000), (3001, 512, 40, 9000), (70000, 512, 96, 50000),
+                                        (70000, 512, 256, 50000), (66000, 512, 256, 90000)])
 def test_head_vs_oracle_seeded(loss_type, margin, Q, D, B, n_id):
     """Larger pools, ragged Q (not a multiple of the 32-column tile), B not a multiple of 16 / above
-    one 64-row block, outlier rows (n_id > Q) — against the float64 oracle."""
+    one 64-row block, the benchmarked batch_size 256 (four row blocks), outlier rows (n_id > Q) — against the
+    float64 oracle.  With D = 512 the non-precise head runs the bf16-shadow sweep (csrc/head16.hip)."""
     T = 3
     case = common.head_case(1000 + Q + B, Q, D, B, T, n_id)
     for precise in (True, False):
@@ -282,5 +284,137 @@ def test_identity_sharded_head_equals_single_pool(loss_type, margin, n_id, world
                 np.testing.assert_allclose(dP.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-4, atol=2e-5)
     whole = torch.cat([h.queue for h in shards], dim=1)
     assert torch.equal(whole, full.queue)
+    for h in shards:
+        assert h.lru.state_dict() == full.lru.state_dict() and h.qp.tolist() == full.qp.tolist()
+
+
+def test_shadow_sweep_matches_fp32_stream_and_tracks_the_pool(monkeypatch):
+    """The bf16 shadow of queue[0] (D = 512, plain bf16 operands): (1) the LDS-DMA sweep over it gives the fp32-streaming
+    kernel's result (same bf16 roundings of W and P; only the summation order and the fixed softmax reference exponent
+    differ), for AM / Arc / SV with outlier rows; (2) after committing passes the shadow IS bf16(queue[0]) bit for bit;
+    (3) a torch-side write to the pool (copy_, as load_state_dict does) rebuilds it."""
+    Q, D, B, T, n_id = 40000, 512, 200, 2, 60000
+    case = common.head_case(99, Q, D, B, T, n_id)
+    for loss_type, margin in (("Arc", 0.5), ("AM", 0.4), ("SV", 0.35)):
+        monkeypatch.setenv("VLSFR_HEAD_SHADOW", "1")
+        fast = make_head(case["queue0"], loss_type, 32.0, margin, False)
+        monkeypatch.setenv("VLSFR_HEAD_SHADOW", "0")
+        slow = make_head(case["queue0"], loss_type, 32.0, margin, False)
+        for t in range(T):
+            xl, yl = case["XL"][t], case["YL"][t]
+            for s_, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+                out = []
+                for head, flag in ((fast, "1"), (slow, "0")):
+                    monkeypatch.setenv("VLSFR_HEAD_SHADOW", flag)
+                    p = torch.from_numpy(case["P"][t, s_]).cuda().requires_grad_(True)
+                    loss = head.run_pass(p, torch.from_numpy(case["G"][t, s_]).cuda(), pl, gl, trans)
+                    loss.backward()
+                    out.append((float(loss), p.grad.cpu().numpy()))
+                np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-5)
+                np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-3, atol=2e-4 * np.abs(out[1][1]).max())
+        assert fast.shadow.t is not None and slow.shadow.t is None
+        assert torch.equal(fast.shadow.t, fast.queue[0].to(torch.bfloat16))
+        assert torch.equal(fast.queue, slow.queue)
+    monkeypatch.setenv("VLSFR_HEAD_SHADOW", "1")
+    rng = np.random.default_rng(5)
+    fast.queue.copy_(torch.from_numpy(common.unit_rows(rng, 2, Q, D)).cuda())
+    p = torch.from_numpy(case["P"][0, 0]).cuda()
+    fast.run_pass(p, torch.from_numpy(case["G"][0, 0]).cuda(), case["XL"][0], case["YL"][0], True)
+    assert torch.equal(fast.shadow.t, fast.queue[0].to(torch.bfloat16))
+
+
+def test_head_metric_size_properties():
+    """The metric's own head: Q = 10 485 760 identities, D = 512, batch_size 256 (BASELINE.json `metric`).  The oracle
+    cannot run here; size-independent properties instead: the result does not depend on the column partition
+    (n_chunks 0 / 256), the rollback pass leaves pool, shadow, LRU and queue_position bit-identical, the commit pass
+    changes exactly the written rows (fp32 master and bf16 shadow), everything is finite, and a dense fp32 PyTorch
+    evaluation of 64 of the rows over the whole pool agrees."""
+    from vlsfr_amd.ffc import build_pool
+    from vlsfr_amd.head import DcpHead
+    Q, D, B = 10 << 20, 512, 256
+    queue0 = build_pool(Q, D, "cuda", seed=7)
+    rng = np.random.default_rng(3)
+    ar = np.arange(Q)
+    labels = rng.choice(Q, size=B, replace=False).astype(np.int64)
+    p_np, g_np = common.unit_rows(rng, B, D), common.unit_rows(rng, B, D)
+    res = []
+    for n_chunks in (0, 256):
+        head = DcpHead(queue0, 32.0, 0.5, "Arc", precise=False, n_chunks=n_chunks)
+        head.lru.restore_arrays(ar.astype(np.int64), ar.astype(np.int32))
+        before_lru, before_qp = head.lru.state_arrays(), head.qp.copy()
+        p = torch.from_numpy(p_np).cuda().requires_grad_(True)
+        g = torch.from_numpy(g_np).cuda()
+        loss = head.run_pass(p, g, labels, labels, True)
+        loss.backward()
+        torch.cuda.synchronize()
+        sh = head.shadow.t
+        assert sh is not None
+        for a0 in range(0, Q, 1 << 20):          # rollback: pool untouched, shadow == bf16(pool)
+            assert torch.equal(sh[a0:a0 + (1 << 20)], queue0[0, a0:a0 + (1 << 20)].to(torch.bfloat16))
+        after = head.lru.state_arrays()
+        assert np.array_equal(before_lru[0], after[0]) and np.array_equal(before_lru[1], after[1])
+        assert np.array_equal(before_qp, head.qp)
+        res.append((float(loss), p.grad.cpu().numpy()))
+        del head
+    (l0, d0), (l1, d1) = res
+    assert np.isfinite(l0) and np.isfinite(d0).all()
+    np.testing.assert_allclose(l0, l1, rtol=1e-5)
+    np.testing.assert_allclose(d0, d1, rtol=2e-3, atol=2e-4 * np.abs(d0).max())
+    # dense fp32 reference for the first 64 rows: every label hits (full residency), rows = qp = 0 -> g goes to row 0
+    # of its slot and variant 2 reads queue[1] there (ones_idx = all label slots)
+    lab = torch.from_numpy(labels).cuda()
+    sub = slice(0, 64)
+    pr = torch.from_numpy(p_np).cuda()[sub].clone().requires_grad_(True)
+    g = torch.from_numpy(g_np).cuda()
+    tot = 0
+    for v in range(2):
+        cos = torch.empty(64, Q, device="cuda")
+        for a0 in range(0, Q, 1 << 21):
+            cos[:, a0:a0 + (1 << 21)] = pr.detach() @ queue0[0, a0:a0 + (1 << 21)].t()
+        cos[:, lab] = pr.detach() @ (g if v == 0 else queue0[1, lab]).t()
+        # loss and gradient of this variant, columns other than the targets treated as constants of p through W
+        z = cos * 32.0
+        gt = cos.gather(1, lab[sub].view(-1, 1))
+        new = gt * np.cos(0.5) - torch.sqrt(1 - gt * gt) * np.sin(0.5)
+        z.scatter_(1, lab[sub].view(-1, 1), new * 32.0)
+        lse = torch.logsumexp(z, dim=1)
+        tot = tot + float((lse - z.gather(1, lab[sub].view(-1, 1)).view(-1)).sum()) / B
+        del cos, z
+    # the 64-row share of the loss is not separable from the kernel's scalar, so compare through a second run on those rows
+    head = DcpHead(queue0, 32.0, 0.5, "Arc", precise=False)
+    head.lru.restore_arrays(ar.astype(np.int64), ar.astype(np.int32))
+    p64 = torch.from_numpy(p_np[:64]).cuda().requires_grad_(True)
+    # same special columns as the full batch: all 256 gallery rows are written, only 64 probe rows are evaluated
+    l64 = head.run_pass(p64, g, labels, labels, True, row_offset=0)
+    np.testing.assert_allclose(float(l64), tot, rtol=2e-3)
+
+
+@pytest.mark.parametrize("loss_type,margin,n_id", [("Arc", 0.5, 12000), ("SV", 0.35, 40000)])
+def test_identity_sharded_head_world8_bf16_shadow(loss_type, margin, n_id):
+    """Eight simulated ranks (the node size the metric is quoted on), D = 512, plain bf16 operands: every rank sweeps
+    the bf16 shadow of ITS slots for all rows with the LDS-DMA kernel; the combined result equals the single-pool head
+    (which runs the same kernel over the whole pool) up to summation order."""
+    from vlsfr_amd.head import ShardedDcpHead
+    Q, D, B, T, world = 32768, 512, 64, 2, 8
+    case = common.head_case(4100, Q, D, B, T, n_id)
+    full = make_head(case["queue0"], loss_type, 32.0, margin, False)
+    q0 = torch.from_numpy(case["queue0"]).cuda()
+    Qs = Q // world
+    shards = [ShardedDcpHead(q0[:, r * Qs:(r + 1) * Qs].contiguous(), r, world, Q, 32.0, margin, loss_type, precise=False)
+              for r in range(world)]
+    for t in range(T):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s_, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            g = torch.from_numpy(case["G"][t, s_]).cuda()
+            p = torch.from_numpy(case["P"][t, s_]).cuda().requires_grad_(True)
+            loss = full.run_pass(p, g, pl, gl, trans)
+            loss.backward()
+            for l, dP in _sharded_pass(shards, p.detach(), g, pl, gl, trans):
+                np.testing.assert_allclose(float(l), float(loss.detach()), rtol=5e-5, atol=1e-5)
+                np.testing.assert_allclose(dP.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-3,
+                                           atol=2e-4 * float(p.grad.abs().max()))
+    assert all(h.shadow.t is not None for h in shards)
+    assert torch.equal(torch.cat([h.queue for h in shards], dim=1), full.queue)
+    assert torch.equal(torch.cat([h.shadow.t for h in shards], dim=0), full.shadow.t)
     for h in shards:
         assert h.lru.state_dict() == full.lru.state_dict() and h.qp.tolist() == full.qp.tolist()

@@ -27,6 +27,7 @@ using namespace vlsfr;
 
 namespace vlsfr {
 extern int g_dw_wgrad_blocks;   // csrc/dw.hip
+int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
 
 namespace {
@@ -1427,6 +1428,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
     extern int g_bn_block_bytes;
     g_bn_block_bytes = value > 0 ? value * 1024 : 65536;
     return VLSFR_OK;
+  }
+  if (name) {
+    const int rc = vlsfr::head_set_option(name, value);   // csrc/head.hip ("head_rb")
+    if (rc <= 0) return rc;
   }
   return fail(VLSFR_EINVAL, "vlsfr_set_option: unknown option");
 }

@@ -19,7 +19,10 @@
 //   * fp32 pool rows are converted to bf16 on the way into LDS (PRECISE: split into hi + lo bf16
 //     and three MFMAs per product ≈ fp32 products, for the fp32-tolerance parity mode).
 //   * per-lane top-k lists feed the hard-negative term of outlier rows (label == -1).
+#include <cstring>
+
 #include "hip_common.h"
+#include "head_sweep16.h"
 
 using namespace vlsfr;
 
@@ -954,7 +957,7 @@ __global__ void head_loss_reduce_kernel(const float* row_loss, int n, float* out
 // queue[rows[i], cols[i]] = g[i]; duplicates resolved "highest batch index wins"
 __global__ __launch_bounds__(256) void pool_scatter_kernel(float* queue, int64_t Q, int D, const float* g,
                                                            const int32_t* rows, const int32_t* cols, int n,
-                                                           int slot_lo) {
+                                                           int slot_lo, __bf16* shadow) {
   const int i = blockIdx.x;
   const int r = rows[i], c = cols[i] - slot_lo;
   if (c < 0 || c >= Q) return;   // slot owned by another rank (identity-sharded pool)
@@ -968,6 +971,24 @@ __global__ __launch_bounds__(256) void pool_scatter_kernel(float* queue, int64_t
   float* dst = queue + ((size_t)r * Q + c) * D;
   const float* src = g + (size_t)i * D;
   for (int d = threadIdx.x; d < D; d += 256) dst[d] = src[d];
+  if (shadow && r == 0) {   // the bf16 shadow mirrors queue[0] (same round-to-nearest-even cast as the in-kernel conversion)
+    __bf16* sd = shadow + (size_t)c * D;
+    for (int d = threadIdx.x; d < D; d += 256) sd[d] = (__bf16)src[d];
+  }
+}
+
+// shadow[q][d] = bf16(queue[0][q][d]): 8 elements per thread, 32 B in / 16 B out
+__global__ __launch_bounds__(256) void pool_shadow_kernel(const float* q0, __bf16* shadow, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const f32x4 a = ((const f32x4*)q0)[2 * i], b = ((const f32x4*)q0)[2 * i + 1];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = (__bf16)a[j];
+      o[4 + j] = (__bf16)b[j];
+    }
+    ((bf16x8*)shadow)[i] = o;
+  }
 }
 
 int round_dp(int D) {
@@ -976,7 +997,11 @@ int round_dp(int D) {
   return dp;
 }
 
+int g_head_rb = 1;   // "head_rb": 16-row blocks per wave of the bf16-shadow sweep (1; 2 = 128-row workgroups, experimental)
+
 struct Plan {
+  bool fast;   // bf16-shadow sweep (head16.hip)
+  int rb;
   int DP, Bp, n_chunks, chunk_cols, n_rowblk;
   size_t off_m, off_l, off_o, off_tv, off_ti, off_cos1, off_cos2, off_thr, off_rowloss, total;
   int n_sets;
@@ -989,6 +1014,27 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   if (c->loss_type < 0 || c->loss_type > 2) return fail(VLSFR_EINVAL, "head: loss_type must be 0 (AM), 1 (Arc) or 2 (SV)");
   if (c->hard_neg < 1 || c->hard_neg > KTOP) return fail(VLSFR_EINVAL, "head: hard_neg must be in [1, 10]");
   pl->DP = round_dp(c->D);
+  // The bf16-shadow sweep: D = 512, plain bf16 operands, and a logit range its fixed reference exponent covers
+  // (head16.hip: scale <= 64; larger scales keep the online-maximum kernel)
+  pl->fast = c->pool_bf16 != nullptr && !c->precise && c->D == SW16_D && c->scale > 0.f && c->scale * LOG2E <= 93.f;
+  pl->rb = 1;
+  if (pl->fast) {
+    pl->rb = (g_head_rb == 2 && c->B > 64) ? 2 : 1;
+    const int rows_wg = 64 * pl->rb;
+    pl->n_rowblk = (c->B + rows_wg - 1) / rows_wg;
+    pl->Bp = pl->n_rowblk * rows_wg;
+    const int64_t tiles = (c->Q + SW16_TQ - 1) / SW16_TQ;
+    // one workgroup per CU (the accumulators and the P fragments own the register file): whole rounds of 256
+    int nch = c->n_chunks > 0 ? c->n_chunks : (256 + pl->n_rowblk - 1) / pl->n_rowblk;
+    if (nch < 8) nch = 8;
+    nch = (nch + 7) & ~7;
+    while ((tiles + nch - 1) / nch > SW16_MAX_TILES) nch *= 2;
+    if (nch > tiles) nch = (int)((tiles + 7) & ~(int64_t)7);
+    const int64_t per = (tiles + nch - 1) / nch;
+    pl->chunk_cols = (int)per * SW16_TQ;
+    pl->n_chunks = (int)((c->Q + pl->chunk_cols - 1) / pl->chunk_cols);
+    pl->n_chunks = (pl->n_chunks + 7) & ~7;
+  } else {
   pl->n_rowblk = (c->B + ROWS_WG - 1) / ROWS_WG;
   pl->Bp = pl->n_rowblk * ROWS_WG;
   int64_t tiles = (c->Q + TQ - 1) / TQ;
@@ -1005,6 +1051,7 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   pl->chunk_cols = (int)per * TQ;
   pl->n_chunks = (int)((c->Q + pl->chunk_cols - 1) / pl->chunk_cols);
   pl->n_chunks = (pl->n_chunks + 7) & ~7;   // multiple of 8 for the XCD-aware block order (extra chunks are empty)
+  }
   pl->n_sets = (c->loss_type == 2) ? 2 : 1;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -1058,16 +1105,84 @@ int dispatch_sweep(int DP, const SweepArgs& a, bool topk, bool sv, dim3 grid, hi
   return fail(VLSFR_EINVAL, "head_sweep: unsupported padded feat_dim %d", DP);
 }
 
+// one sweep per set (SV: one per variant) through whichever kernel the plan selected
+int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws, const float* thr, bool sv, bool want_topk,
+               hipStream_t st) {
+  const size_t rowsz = (size_t)pl.n_chunks * pl.Bp;
+  const dim3 grid(pl.n_chunks * pl.n_rowblk);
+  for (int set = 0; set < pl.n_sets; ++set) {
+    a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
+    a.part_l = (float*)(ws + pl.off_l) + set * rowsz;
+    a.part_o = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
+    a.sv_thr = sv ? thr + (size_t)set * pl.Bp : nullptr;
+    const bool topk = want_topk && set == 0;   // top-k uses raw cosines: variant independent
+    int rc;
+    if (pl.fast) {
+      Sweep16Args f;
+      f.p = a.p;
+      f.w16 = (const uint16_t*)cfg->pool_bf16;
+      f.Q = a.Q;
+      f.B = a.B;
+      f.chunk_cols = a.chunk_cols;
+      f.n_chunks = a.n_chunks;
+      f.special_col = a.special_col;
+      f.n_special = a.n_special;
+      f.pool_label = a.pool_label;
+      f.qscale = a.qscale;
+      f.sv_thr = a.sv_thr;
+      f.sv_t = a.sv_t;
+      f.part_m = a.part_m;
+      f.part_l = a.part_l;
+      f.part_o = a.part_o;
+      f.topk_val = a.topk_val;
+      f.topk_idx = a.topk_idx;
+      f.Bp = a.Bp;
+      f.n_rowblk = a.n_rowblk;
+      f.slot_lo = a.slot_lo;
+      rc = launch_sweep16(f, pl.rb, topk, sv, st);
+    } else {
+      rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st) : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
+    }
+    if (rc != VLSFR_OK) return rc;
+  }
+  return VLSFR_OK;
+}
+
 }  // namespace
+
+namespace vlsfr {
+int head_set_option(const char* name, int32_t value) {
+  if (!strcmp(name, "head_rb")) {
+    if (value != 1 && value != 2) return fail(VLSFR_EINVAL, "head_rb must be 1 or 2");
+    g_head_rb = value;
+    return VLSFR_OK;
+  }
+  return 1;   // not a head option
+}
+}  // namespace vlsfr
 
 extern "C" {
 
+size_t vlsfr_head_cfg_size(void) { return sizeof(vlsfr_head_cfg); }
+
+int vlsfr_pool_shadow_build(const float* queue0, void* shadow_bf16, int64_t Q, int32_t D, void* stream) {
+  if (!queue0 || !shadow_bf16 || Q <= 0 || D <= 0 || D % 8 != 0)
+    return fail(VLSFR_EINVAL, "vlsfr_pool_shadow_build: bad argument (D must be a multiple of 8)");
+  const size_t n8 = (size_t)Q * D / 8;
+  const size_t blocks = (n8 + 255) / 256;
+  hipLaunchKernelGGL(pool_shadow_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     queue0, (__bf16*)shadow_bf16, n8);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_pool_shadow_build launch");
+  return VLSFR_OK;
+}
+
 int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g, const int32_t* rows, const int32_t* cols,
-                       int32_t n, int32_t slot_lo, void* stream) {
+                       int32_t n, int32_t slot_lo, void* shadow_bf16, void* stream) {
   if (!queue || !g || !rows || !cols || Q <= 0 || D <= 0 || n < 0)
     return fail(VLSFR_EINVAL, "vlsfr_pool_scatter: bad argument");
   if (n == 0) return VLSFR_OK;
-  hipLaunchKernelGGL(pool_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, queue, Q, D, g, rows, cols, n, slot_lo);
+  hipLaunchKernelGGL(pool_scatter_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, queue, Q, D, g, rows, cols, n, slot_lo,
+                     (__bf16*)shadow_bf16);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_pool_scatter launch");
   return VLSFR_OK;
 }
@@ -1132,17 +1247,8 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
   a.Bp = pl.Bp;
   a.n_rowblk = pl.n_rowblk;
   a.slot_lo = cfg->slot_lo;
-  const dim3 grid(pl.n_chunks * pl.n_rowblk);
-  for (int set = 0; set < pl.n_sets; ++set) {
-    a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
-    a.part_l = (float*)(ws + pl.off_l) + set * rowsz;
-    a.part_o = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
-    a.sv_thr = sv ? thr + set * pl.Bp : nullptr;
-    const bool topk = (n_out > 0) && set == 0;   // top-k uses raw cosines: variant independent
-    rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st)
-                      : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
-    if (rc != VLSFR_OK) return rc;
-  }
+  rc = run_sweeps(cfg, pl, a, ws, thr, sv, n_out > 0, st);
+  if (rc != VLSFR_OK) return rc;
   FinishArgs f;
   f.g = g;
   f.queue = queue;
@@ -1244,17 +1350,8 @@ static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const f
   a.Bp = pl.Bp;
   a.n_rowblk = pl.n_rowblk;
   a.slot_lo = cfg->slot_lo;
-  const dim3 grid(pl.n_chunks * pl.n_rowblk);
-  for (int set = 0; set < pl.n_sets; ++set) {   // SV: one sweep per variant (the threshold differs)
-    a.part_m = (float*)(ws + pl.off_m) + set * rowsz;
-    a.part_l = (float*)(ws + pl.off_l) + set * rowsz;
-    a.part_o = (float*)(ws + pl.off_o) + set * rowsz * pl.DP;
-    a.sv_thr = sv ? thr + (size_t)set * pl.Bp : nullptr;
-    const bool topk = n_pos < B && set == 0;    // top-k uses raw cosines: variant independent
-    rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st)
-                      : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
-    if (rc != VLSFR_OK) return rc;
-  }
+  rc = run_sweeps(cfg, pl, a, ws, thr, sv, n_pos < B, st);
+  if (rc != VLSFR_OK) return rc;
   ShardFinishArgs sf;
   FinishArgs& f = sf.f;
   f.g = g;

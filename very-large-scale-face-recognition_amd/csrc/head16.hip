@@ -38,10 +38,9 @@ constexpr int TILE_B = TQ * ROWB;     // 33 792
 constexpr int NS = 4;                 // ring stages
 constexpr int KS = DP / 32;           // k-steps of the first product
 constexpr int NB = DP / 16;           // 16-column blocks of the second product
-constexpr int PF1 = 4;                // k-steps of fragment reads in flight (first product)
-constexpr int PF2 = 4;                // column blocks of transposed reads in flight (second product)
+constexpr int PF1 = 2;                // k-steps of fragment reads in flight (first product)
+constexpr int PF2 = 2;                // column blocks of transposed reads in flight (second product)
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float DEFER_THR = 12.0f;    // deferred-rescale threshold in log2 units
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
@@ -104,13 +103,14 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
 
   // ---- P fragments (B operand of S^T = W . P^T): lane holds P[row 16 rb + r16][32 ks + 8 h + j]
   bf16x8 pf[RB][KS];
-  float sv_thr[RB];
+  float sv_thr[RB], m_ref[RB];
   bool is_out[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int prow = row_base + 16 * rb + r16;
     const bool ok = wave_active && prow < a.B;
     const f32x4* src = (const f32x4*)(a.p + (size_t)(ok ? prow : 0) * DP + h * 8);
+    float nrm = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       f32x4 v0 = src[ks * 8], v1 = src[ks * 8 + 1];
@@ -122,8 +122,19 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
       for (int j = 0; j < 4; ++j) {
         pf[rb][ks][j] = (__bf16)v0[j];
         pf[rb][ks][4 + j] = (__bf16)v1[j];
+        nrm += v0[j] * v0[j] + v1[j] * v1[j];
       }
+      // at most four k-steps of fp32 loads in flight: the accumulators and the bf16 fragments own the register file
+      if ((ks & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    // Fixed reference exponent of the row (log2 units).  Pool rows are unit vectors (every row of queue[] is an
+    // F.normalize output: ffc.py:30 and the gallery embeddings written at ffc.py:182), so |cos| <= |p| and every
+    // logit lies in [-b, b], b = qscale * |p| (SV: up to 1.4 b, ffc.py:124).  With m_ref = b_hi - 60 the terms
+    // 2^(logit - m_ref) stay below 2^60 (their sum over a chunk far below the fp32 range) and above 2^-126 for
+    // scale <= 64 — the online maximum and the O rescale of the fp32-streaming kernel are not needed.
+    nrm = lane_step_sum<16>(nrm);
+    nrm = lane_step_sum<32>(nrm);
+    m_ref[rb] = a.qscale * __builtin_sqrtf(nrm) * (SV ? (a.sv_t + a.sv_t - 1.f) : 1.f) - 60.f;
     sv_thr[rb] = (SV && ok) ? a.sv_thr[prow] : 0.f;
     is_out[rb] = TOPK && ok && a.pool_label[prow] < 0;
   }
@@ -134,10 +145,9 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
   for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) oacc[rb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_ref[RB], l_part[RB], tk_thr[RB];
+  float l_part[RB], tk_thr[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    m_ref[rb] = NEG_BIG;   // reference exponent of row r16 (log2 units), identical in the 4 h-lanes
     l_part[rb] = 0.f;      // this lane's share of sum 2^(s - m_ref)
     tk_thr[rb] = NEG_BIG;  // admission threshold of this lane's candidate list
   }
@@ -181,6 +191,15 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
     __builtin_amdgcn_s_barrier();                                           // everybody's; and tile t - 1 is no longer read
     issue(t + NS - 1);                                                      // into the slot of tile t - 1
     if (wave_active) {
+      // register classes, stated once per tile: the O accumulators own the accumulator file, the P fragments
+      // stay in architectural VGPRs (left to itself the allocator spills P and reloads it every k-step at RB = 2)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(oacc[rb][nb]));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(pf[rb][ks]));
+      }
       const uint32_t sb = lds0 + (uint32_t)((t % NS) * TILE_B);
       const uint32_t a1 = sb + off1, a2 = sb + off2;
       const uint32_t word = lds_r32(bits0 + 4u * (uint32_t)t);
@@ -225,9 +244,6 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
       bf16x8 pa[RB];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
-        float s[8], av[8];
-        bool valid[8];
-        float tmax = NEG_BIG;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int jb = q >> 2, e = q & 3;
@@ -262,34 +278,11 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
               fac = a.sv_t;
             }
           }
-          av[q] = fac;
-          valid[q] = ok;
-          s[q] = ok ? c * a.qscale : NEG_BIG;
-          tmax = fmaxf(tmax, s[q]);
-        }
-        tmax = lane_step_max<16>(tmax);
-        tmax = lane_step_max<32>(tmax);
-        // deferred rescale: move the reference exponent only when the row maximum outgrows it
-        const bool grow = tmax > m_ref[rb] + DEFER_THR;
-        if (__any(grow)) {
-          const float m_new = grow ? tmax : m_ref[rb];
-          const float alpha = grow ? __builtin_amdgcn_exp2f(m_ref[rb] - m_new) : 1.f;
-          m_ref[rb] = m_new;
-          l_part[rb] *= alpha;
-          float al[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) al[e] = __shfl(alpha, 4 * h + e, 64);   // O rows are 4h + e
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) oacc[rb][nb][e] *= al[e];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float pe = __builtin_amdgcn_exp2f(s[q] - m_ref[rb]);
-          if (!plain) pe = valid[q] ? pe : 0.f;
+          // 2^(logit - m_ref) against the row's FIXED reference exponent: no running maximum, no rescale of O
+          float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(c, a.qscale, -m_ref[rb]));
+          if (!plain) pe = ok ? pe : 0.f;
           l_part[rb] += pe;
-          pa[rb][q] = (__bf16)(SV ? pe * av[q] : pe);
+          pa[rb][q] = (__bf16)(SV ? pe * fac : pe);
         }
       }
       // ================= second product: O[i][d] += sum_j P~[i][j] W[j][d]

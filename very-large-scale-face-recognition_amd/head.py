@@ -22,7 +22,41 @@ class HeadCfg(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("D", ctypes.c_int32), ("Q", ctypes.c_int64),
                 ("loss_type", ctypes.c_int32), ("scale", ctypes.c_float), ("margin", ctypes.c_float),
                 ("hard_neg", ctypes.c_int32), ("precise", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
-                ("slot_lo", ctypes.c_int32), ("n_rows_total", ctypes.c_int32)]
+                ("slot_lo", ctypes.c_int32), ("n_rows_total", ctypes.c_int32), ("pool_bf16", ctypes.c_void_p)]
+
+
+def _check_abi(L):
+    """The ctypes mirror of vlsfr_head_cfg must be the struct libvlsfr.so was compiled with."""
+    L.vlsfr_head_cfg_size.restype = ctypes.c_size_t
+    n = L.vlsfr_head_cfg_size()
+    if n != ctypes.sizeof(HeadCfg):
+        raise _lib.VlsfrError("vlsfr_head_cfg: library has %d bytes, binding has %d — rebuild libvlsfr.so" %
+                              (n, ctypes.sizeof(HeadCfg)))
+
+
+class PoolShadow(object):
+    """bf16 mirror of queue[0] that the head sweep streams (include/vlsfr.h section 3): built on first use,
+    kept current by vlsfr_pool_scatter, rebuilt when queue was modified through torch (its version counter moved:
+    load_state_dict, copy_).  Only for D = 512 and plain bf16 operands — the cases csrc/head16.hip covers."""
+
+    def __init__(self, queue):
+        self.queue = queue
+        self.t = None
+        self.version = None
+
+    def ptr(self, enabled):
+        q = self.queue
+        if not enabled or q.shape[2] != 512 or os.environ.get("VLSFR_HEAD_SHADOW", "1") == "0":
+            return None
+        if self.t is None:
+            self.t = torch.empty(q.shape[1], q.shape[2], dtype=torch.bfloat16, device=q.device)
+        if self.version != q._version:
+            fn = _lib.lib().vlsfr_pool_shadow_build
+            fn.restype = ctypes.c_int
+            _lib.check(fn(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(self.t.data_ptr()), ctypes.c_int64(q.shape[1]),
+                          ctypes.c_int32(q.shape[2]), _stream_ptr()), "vlsfr_pool_shadow_build")
+            self.version = q._version
+        return self.t.data_ptr()
 
 
 def _stream_ptr():
@@ -81,7 +115,9 @@ class DcpHead(object):
         assert loss_type in LOSS_TYPES
         assert queue.dim() == 3 and queue.shape[0] == 2 and queue.dtype == torch.float32
         self.L = _lib.lib()
+        _check_abi(self.L)
         self.queue = queue                       # [2, Q, D] fp32, device, contiguous (shared with FFC.queue)
+        self.shadow = PoolShadow(queue)
         self.Q, self.D = int(queue.shape[1]), int(queue.shape[2])
         self.scale, self.margin, self.loss_type = float(scale), float(margin), loss_type
         self.precise, self.n_chunks = bool(precise), int(n_chunks or os.environ.get('VLSFR_HEAD_CHUNKS', 0))
@@ -94,10 +130,10 @@ class DcpHead(object):
     # -------------------------------------------------------------------------------------------
     def _cfg(self, B, B_total=0):
         return HeadCfg(B, self.D, self.Q, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), self.n_chunks, 0, B_total)
+                       int(self.precise), self.n_chunks, 0, B_total, self.shadow.ptr(not self.precise))
 
     def _workspace(self, cfg, device):
-        key = (cfg.B, cfg.n_rows_total, str(device))
+        key = (cfg.B, cfg.n_rows_total, str(device), cfg.pool_bf16, cfg.precise, cfg.loss_type, cfg.scale)
         if self._ws_key != key:
             self.L.vlsfr_head_workspace_bytes.restype = ctypes.c_size_t
             self.L.vlsfr_head_workspace_bytes.argtypes = [ctypes.POINTER(HeadCfg)]
@@ -173,7 +209,8 @@ class DcpHead(object):
             sc = self.L.vlsfr_pool_scatter
             sc.restype = ctypes.c_int
             rc = sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Q), ctypes.c_int32(self.D),
-                    ctypes.c_void_p(gd.data_ptr()), at(10), at(11), ctypes.c_int32(n), ctypes.c_int32(0), _stream_ptr())   # ffc.py:182
+                    ctypes.c_void_p(gd.data_ptr()), at(10), at(11), ctypes.c_int32(n), ctypes.c_int32(0),
+                    ctypes.c_void_p(self.shadow.ptr(True) if self.shadow.t is not None else None), _stream_ptr())   # ffc.py:182
             _lib.check(rc, "vlsfr_pool_scatter")
         self._keep = (tab_d, pd, gd)     # keep operands alive until the next pass is enqueued
         return _HeadFn.apply(p, loss.reshape(()), dP)
@@ -193,7 +230,9 @@ class ShardedDcpHead(object):
 
     def __init__(self, queue_shard, rank, world, Q_total, scale, margin, loss_type, precise=False, lru=None, qp=None):
         self.L = _lib.lib()
+        _check_abi(self.L)
         self.queue = queue_shard                 # [2, Qs, D] fp32 device
+        self.shadow = PoolShadow(queue_shard)
         self.rank, self.world = rank, world
         self.Qs, self.D, self.Q = int(queue_shard.shape[1]), int(queue_shard.shape[2]), int(Q_total)
         assert self.Qs * world == self.Q
@@ -208,7 +247,7 @@ class ShardedDcpHead(object):
 
     def _cfg(self, B):
         return HeadCfg(B, self.D, self.Qs, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), 0, self.slot_lo, 0)
+                       int(self.precise), 0, self.slot_lo, 0, self.shadow.ptr(not self.precise))
 
     def begin(self, p_all, g_all, probe_label, gallery_label, transactional):
         """Bookkeeping of one pass (identical on every rank) and, for SV, this rank's view of the hard-example
@@ -218,11 +257,12 @@ class ShardedDcpHead(object):
         dev = p_all.device
         tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
         cfg = self._cfg(B)
-        if self._ws_key != B:
+        key = (B, cfg.pool_bf16, cfg.precise, cfg.loss_type, cfg.scale)
+        if self._ws_key != key:
             fn = self.L.vlsfr_head_workspace_bytes
             fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.POINTER(HeadCfg)]
             self._ws = torch.empty(fn(ctypes.byref(cfg)), dtype=torch.uint8, device=dev)
-            self._ws_key = B
+            self._ws_key = key
         pd, gd = p_all.detach().float().contiguous(), g_all.detach().float().contiguous()
         st = dict(tab_d=tab_d, plan=plan, cfg=cfg, pd=pd, gd=gd, transactional=transactional, thr=None,
                   label=torch.from_numpy(tab[:B].copy()).to(dev))
@@ -329,6 +369,8 @@ class ShardedDcpHead(object):
             at = lambda j: ctypes.c_void_p(base + 4 * j * n)
             _lib.check(sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Qs), ctypes.c_int32(D),
                           ctypes.c_void_p(st["gd"].data_ptr()), at(10), at(11), ctypes.c_int32(n),
-                          ctypes.c_int32(self.slot_lo), _stream_ptr()), "vlsfr_pool_scatter")
+                          ctypes.c_int32(self.slot_lo),
+                          ctypes.c_void_p(self.shadow.ptr(True) if self.shadow.t is not None else None), _stream_ptr()),
+                       "vlsfr_pool_scatter")
         self._keep = st
         return row_loss.sum(), dP
