@@ -1430,7 +1430,7 @@ int vlsfr_set_option(const char* name, int32_t value) {
     return VLSFR_OK;
   }
   if (name) {
-    const int rc = vlsfr::head_set_option(name, value);   // csrc/head.hip ("head_rb")
+    const int rc = vlsfr::head_set_option(name, value);   // csrc/head.hip ("head_variant")
     if (rc <= 0) return rc;
   }
   return fail(VLSFR_EINVAL, "vlsfr_set_option: unknown option");

@@ -997,11 +997,11 @@ int round_dp(int D) {
   return dp;
 }
 
-int g_head_rb = 1;   // "head_rb": 16-row blocks per wave of the bf16-shadow sweep (1; 2 = 128-row workgroups, experimental)
+int g_head_variant = -1;   // "head_variant": bf16-shadow sweep geometry (head_sweep16.h); -1 = by batch size
 
 struct Plan {
   bool fast;   // bf16-shadow sweep (head16.hip)
-  int rb;
+  int variant;
   int DP, Bp, n_chunks, chunk_cols, n_rowblk;
   size_t off_m, off_l, off_o, off_tv, off_ti, off_cos1, off_cos2, off_thr, off_rowloss, total;
   int n_sets;
@@ -1017,10 +1017,10 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   // The bf16-shadow sweep: D = 512, plain bf16 operands, and a logit range its fixed reference exponent covers
   // (head16.hip: scale <= 64; larger scales keep the online-maximum kernel)
   pl->fast = c->pool_bf16 != nullptr && !c->precise && c->D == SW16_D && c->scale > 0.f && c->scale * LOG2E <= 93.f;
-  pl->rb = 1;
+  pl->variant = 0;
   if (pl->fast) {
-    pl->rb = (g_head_rb == 2 && c->B > 64) ? 2 : 1;
-    const int rows_wg = 64 * pl->rb;
+    pl->variant = g_head_variant >= 0 ? g_head_variant : (c->B > 64 ? 1 : 0);
+    const int rows_wg = sweep16_rows_per_wg(pl->variant);
     pl->n_rowblk = (c->B + rows_wg - 1) / rows_wg;
     pl->Bp = pl->n_rowblk * rows_wg;
     const int64_t tiles = (c->Q + SW16_TQ - 1) / SW16_TQ;
@@ -1139,7 +1139,7 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
       f.Bp = a.Bp;
       f.n_rowblk = a.n_rowblk;
       f.slot_lo = a.slot_lo;
-      rc = launch_sweep16(f, pl.rb, topk, sv, st);
+      rc = launch_sweep16(f, pl.variant, topk, sv, st);
     } else {
       rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st) : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
     }
@@ -1152,9 +1152,9 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
 
 namespace vlsfr {
 int head_set_option(const char* name, int32_t value) {
-  if (!strcmp(name, "head_rb")) {
-    if (value != 1 && value != 2) return fail(VLSFR_EINVAL, "head_rb must be 1 or 2");
-    g_head_rb = value;
+  if (!strcmp(name, "head_variant")) {
+    if (value < -1 || value > 2) return fail(VLSFR_EINVAL, "head_variant must be -1 (auto), 0, 1 or 2");
+    g_head_variant = value;
     return VLSFR_OK;
   }
   return 1;   // not a head option

@@ -67,8 +67,10 @@ __device__ __forceinline__ uint32_t lds_r32(uint32_t addr) {
   return v;
 }
 
-template <int RB, bool TOPK, bool SV>
-__global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
+template <int NW, int RB, bool TOPK, bool SV>
+__global__ __launch_bounds__(64 * NW, NW / 4) void head_sweep16_kernel(Sweep16Args a) {
+  constexpr int NT = 64 * NW;        // threads per workgroup
+  constexpr int DR = TQ / NW;        // pool rows one wave fetches per tile (one LDS-DMA each)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* bits = (uint32_t*)(smem + NS * TILE_B);
 
@@ -88,14 +90,14 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
   const int64_t c1 = (c0 + a.chunk_cols < a.Q) ? c0 + a.chunk_cols : a.Q;
   const int ncols = c1 > c0 ? (int)(c1 - c0) : 0;
   const int ntiles = (ncols + TQ - 1) / TQ;
-  const int row_base = rowblk * (64 * RB) + wave * (16 * RB);
+  const int row_base = rowblk * (16 * RB * NW) + wave * (16 * RB);
   const bool wave_active = row_base < a.B;     // wave-uniform
 
   // ---- special-column bitmap of this chunk: one 32-bit word per tile (plain LDS ops: no DMA is pending yet)
   const int nwords = a.chunk_cols / TQ;
-  for (int i = tid; i < nwords; i += 256) bits[i] = 0u;
+  for (int i = tid; i < nwords; i += NT) bits[i] = 0u;
   __syncthreads();
-  for (int i = tid; i < a.n_special; i += 256) {
+  for (int i = tid; i < a.n_special; i += NT) {
     const int64_t c = (int64_t)a.special_col[i] - a.slot_lo;   // special columns carry global slot ids
     if (c >= c0 && c < c1) atomicOr(&bits[(c - c0) >> 5], 1u << ((c - c0) & 31));
   }
@@ -167,15 +169,15 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
     }
   }
 
-  // ---- LDS-DMA: wave w fetches rows 8w .. 8w + 7 of a tile, one 1-KiB instruction per pool row
+  // ---- LDS-DMA: wave w fetches rows DR w .. DR w + DR - 1 of a tile, one 1-KiB instruction per pool row
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.w16 + (size_t)(ncols > 0 ? c0 : 0) * DP), 0, ncols * (DP * 2), 0x00020000);
   const int voff = lane * 16;
   auto issue = [&](int t) {
-    char* st = smem + (t % NS) * TILE_B + wave * 8 * ROWB;
-    const int soff = (t * TQ + wave * 8) * (DP * 2);   // rows past the chunk end: out of range -> zeros
+    char* st = smem + (t % NS) * TILE_B + wave * DR * ROWB;
+    const int soff = (t * TQ + wave * DR) * (DP * 2);   // rows past the chunk end: out of range -> zeros
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < DR; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(st + i * ROWB), 16, voff, soff + i * (DP * 2), 0, 0);
   };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
   for (int t = 0; t < NS - 1; ++t) issue(t);
 
   for (int t = 0; t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 8) : "memory");   // this wave's rows of tile t have landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * DR) : "memory");   // this wave's rows of tile t have landed
     __builtin_amdgcn_s_barrier();                                           // everybody's; and tile t - 1 is no longer read
     issue(t + NS - 1);                                                      // into the slot of tile t - 1
     if (wave_active) {
@@ -195,8 +197,10 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
       // stay in architectural VGPRs (left to itself the allocator spills P and reloads it every k-step at RB = 2)
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
+        if constexpr (NW == 4) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(oacc[rb][nb]));
+          for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+a"(oacc[rb][nb]));
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(pf[rb][ks]));
       }
@@ -333,16 +337,16 @@ __global__ __launch_bounds__(256, 1) void head_sweep16_kernel(Sweep16Args a) {
   }
 }
 
-template <int RB>
-int launch_rb(const Sweep16Args& a, bool topk, bool sv, hipStream_t st) {
+template <int NW, int RB>
+int launch_v(const Sweep16Args& a, bool topk, bool sv, hipStream_t st) {
   const size_t lds = sweep16_lds_bytes(a.chunk_cols);
   const dim3 grid(a.n_chunks * a.n_rowblk);
 #define VLSFR_SWEEP16(T, S)                                                                                      \
   do {                                                                                                          \
-    auto kern = head_sweep16_kernel<RB, T, S>;                                                                  \
+    auto kern = head_sweep16_kernel<NW, RB, T, S>;                                                              \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return hip_fail(e, "head_sweep16: hipFuncSetAttribute");                               \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);                                                      \
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), lds, st, a);                                                  \
   } while (0)
   if (topk && sv) VLSFR_SWEEP16(true, true);
   else if (topk) VLSFR_SWEEP16(true, false);
@@ -359,12 +363,16 @@ namespace vlsfr {
 
 size_t sweep16_lds_bytes(int chunk_cols) { return (size_t)NS * TILE_B + (size_t)(chunk_cols / TQ) * 4 + 16; }
 
-int launch_sweep16(const Sweep16Args& a, int RB, bool topk, bool sv, hipStream_t st) {
-  if (a.chunk_cols % TQ != 0 || a.chunk_cols / TQ > SW16_MAX_TILES || a.n_chunks % 8 != 0 || a.Bp != a.n_rowblk * 64 * RB)
+int sweep16_rows_per_wg(int variant) { return variant == 0 ? 64 : 128; }
+
+int launch_sweep16(const Sweep16Args& a, int variant, bool topk, bool sv, hipStream_t st) {
+  if (variant < 0 || variant > 2) return fail(VLSFR_EINVAL, "head_sweep16: variant must be 0, 1 or 2");
+  if (a.chunk_cols % TQ != 0 || a.chunk_cols / TQ > SW16_MAX_TILES || a.n_chunks % 8 != 0 ||
+      a.Bp != a.n_rowblk * sweep16_rows_per_wg(variant))
     return fail(VLSFR_EINVAL, "head_sweep16: inconsistent plan (chunk_cols %d, n_chunks %d, Bp %d)", a.chunk_cols, a.n_chunks, a.Bp);
-  if (RB == 1) return launch_rb<1>(a, topk, sv, st);
-  if (RB == 2) return launch_rb<2>(a, topk, sv, st);
-  return fail(VLSFR_EINVAL, "head_sweep16: RB must be 1 or 2");
+  if (variant == 0) return launch_v<4, 1>(a, topk, sv, st);
+  if (variant == 1) return launch_v<8, 1>(a, topk, sv, st);
+  return launch_v<4, 2>(a, topk, sv, st);
 }
 
 }  // namespace vlsfr

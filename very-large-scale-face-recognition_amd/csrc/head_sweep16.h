@@ -28,14 +28,18 @@ struct Sweep16Args {
   float* part_o;             // [n_chunks, Bp, 512]
   float* topk_val;           // [n_chunks, Bp, 4, KTOP]
   int32_t* topk_idx;
-  int32_t Bp;                // n_rowblk * 64 * RB
+  int32_t Bp;                // n_rowblk * rows per workgroup
   int32_t n_rowblk;
   int32_t slot_lo;
 };
 
-// RB = 16-row blocks per wave: 1 (64 probe rows per workgroup; B <= 64, HBM-bound) or 2 (128 rows per
-// workgroup; MFMA-bound).  grid = n_chunks * n_rowblk workgroups of 256 threads.
-int launch_sweep16(const Sweep16Args& a, int RB, bool topk, bool sv, hipStream_t st);
+// variant 0: 4 waves x 16 rows (64 probe rows per workgroup, one wave per SIMD) — batch <= 64, HBM-bound;
+// variant 1: 8 waves x 16 rows (128 rows per workgroup, two waves per SIMD sharing one LDS ring: the softmax and
+//            the LDS latencies of one wave run under the MFMAs of its SIMD partner);
+// variant 2: 4 waves x 32 rows (128 rows, one wave per SIMD, every W fragment feeds two MFMAs) — experimental.
+// grid = n_chunks * n_rowblk workgroups, Bp = n_rowblk * sweep16_rows_per_wg(variant).
+int launch_sweep16(const Sweep16Args& a, int variant, bool topk, bool sv, hipStream_t st);
+int sweep16_rows_per_wg(int variant);
 size_t sweep16_lds_bytes(int chunk_cols);
 
 }  // namespace vlsfr
