@@ -238,7 +238,7 @@ def main():
         dt = float(t.item())
     def collect():
         out = {}
-        for fam, name in ((0, "conv_igemm_kernel"), (1, "conv_wgrad_kernel")):
+        for fam, name in ((0, "conv_igemm_kernel"), (1, "conv_wgrad_kernel"), (2, "head_sweep_kernel")):
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
             L.vlsfr_profile_collect.restype = ctypes.c_int
             _lib.check(L.vlsfr_profile_collect(ctypes.c_int32(fam), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
@@ -282,6 +282,14 @@ def main():
                                       note="streams overlap: launch durations include shared-chip time"),
                     other={k: dict(total_ms=round(v[0], 2), tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                                    launches=int(v[2])) for k, v in fams.items() if k != dom})
+    hs = fams.get("head_sweep_kernel")
+    if hs and hs[2] > 0 and hs[0] > 0:
+        # the class matmul north_star singles out: MFMA fraction of both contractions (4 B Q D FLOPs per sweep) and
+        # the HBM rate of the pool bytes it streams (bf16 shadow: Q * D * 2 per sweep)
+        pool_bytes = Q // max(world if sharded else 1, 1) * args.feat * 2
+        roofline["other"]["head_sweep_kernel"].update(
+            avg_launch_us=round(hs[0] * 1e3 / hs[2], 1), mfma_frac=round(hs[1] / (hs[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            pool_gb_per_s=round(pool_bytes * hs[2] / (hs[0] * 1e-3) / 1e9, 1))
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be collected from inside this
     # process, so the figure measured by rocprofv3 --pmc on this same command (profiles/) is attached
     # when the configuration matches

@@ -361,10 +361,11 @@ int vlsfr_sgd_nesterov(const int64_t* table_dev, int32_t n_chunks, float lr, flo
 int vlsfr_ema(const int64_t* table_dev, int32_t n_chunks, float m, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * 9. Measurement support: while enabled, every launch of the convolution kernel families is
- *    bracketed by HIP events on its own stream (family 0: conv_igemm = forward + input gradient,
- *    family 1: conv_wgrad).  vlsfr_profile_collect sums elapsed time, algorithmic FLOPs
- *    (2 * pixels * Cout * R*S*Cin per launch) and launch count.  Used by bench.py's roofline leg.
+ * 9. Measurement support: while enabled, every launch of the profiled kernel families is bracketed by HIP
+ *    events on its own stream — family 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep.
+ *    vlsfr_profile_collect sums elapsed time, ALGORITHMIC FLOPs (convolutions: 2 * forward output positions *
+ *    Cout * R*S*Cin, so a stride-2 input gradient is priced at its forward's positions and the stem at its 27 real
+ *    taps; head sweep: 4 * B * Q * D) and launch count.  Used by bench.py's roofline leg.
  * ---------------------------------------------------------------------------------------- */
 void vlsfr_profile_enable(int32_t on);
 /* tuning switches for A/B measurements: "conv_glds" (1 = LDS-DMA pipelined conv kernel, default;

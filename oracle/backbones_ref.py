@@ -7,8 +7,17 @@ driven by a flat state dict that uses the reference's parameter names:
 Both run in training mode (batch statistics, running-stat update with momentum 0.1, eps 1e-5),
 because the reference never calls .eval() on either net (ffc.py:22-23, main.py:116-121).
 
-Pinned against the reference itself: tests/golden/backbone_*.npz were produced by importing the
-reference modules in the build container (tests/golden/make_golden.py).
+Pinned against the reference itself through the whole-step fixtures tests/golden/step_*.npz, produced by
+importing the reference modules in the build container (tests/golden/make_golden.py) and replayed by
+tests/test_oracle_golden.py.
+
+`emulate_bf16=True` keeps the same float64 arithmetic but rounds to bfloat16 at exactly the points where the
+MI355X path stores a tensor in bf16 (csrc/iresnet.cpp, csrc/mobilenet.cpp): the image, MFMA-convolution weights,
+every convolution output (BatchNorm statistics are taken from the rounded tensor, as the conv epilogue does), every
+BatchNorm/PReLU/residual output, and in the backward pass every activation gradient (convolution input gradients,
+BatchNorm input gradients, the gradient entering the fc / linear1 contraction).  What is left between the two is
+summation order and fp32-vs-fp64 accumulation, so whole-step GRADIENTS can be compared tightly
+(tests/test_step_gpu.py) instead of through the bf16 noise band.  With the flag off nothing changes.
 """
 import math
 
@@ -111,6 +120,55 @@ def trainable(name):
 
 
 # ----------------------------------------------------------------------------------------------
+# bf16 storage emulation (see module docstring)
+# ----------------------------------------------------------------------------------------------
+def _bf16(t):
+    return t.to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundBoth(torch.autograd.Function):
+    """A tensor the device stores in bf16: rounded in the forward pass, its gradient rounded in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose gradient is rounded: an input gradient the device writes to a bf16 buffer before it is summed
+    with another contribution."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+class Emu(object):
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def R(self, x):
+        return _RoundBoth.apply(x) if self.on else x
+
+    def G(self, x):
+        return _RoundGrad.apply(x) if self.on else x
+
+    def W(self, w):          # bf16 operand copy of an fp32 master weight (gradient goes to the master)
+        return w + (_bf16(w.detach()) - w.detach()) if self.on else w
+
+    def X(self, x):          # the input image (no gradient)
+        return _bf16(x) if self.on else x
+
+
+# ----------------------------------------------------------------------------------------------
 # forward passes (training-mode BN; running stats updated in place in `sd`)
 # ----------------------------------------------------------------------------------------------
 def _bn_train(sd, name, x):
@@ -120,64 +178,71 @@ def _bn_train(sd, name, x):
     return y
 
 
-def iresnet_forward(sd, x, layers):
-    h = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
-    h = F.prelu(_bn_train(sd, "bn1", h), sd["prelu.weight"])
+def iresnet_forward(sd, x, layers, emulate_bf16=False):
+    E = Emu(emulate_bf16)
+    conv = lambda h, name, stride, pad: E.R(F.conv2d(E.G(h), E.W(sd[name + ".weight"]), None, stride, pad))
+    h = conv(E.X(x), "conv1", 1, 1)
+    h = E.R(F.prelu(_bn_train(sd, "bn1", h), sd["prelu.weight"]))
     for li, nblk in enumerate(layers, start=1):
         for bi in range(nblk):
             pre = "layer%d.%d" % (li, bi)
             stride = 2 if bi == 0 else 1
-            o = _bn_train(sd, pre + ".bn1", h)
-            o = F.conv2d(o, sd[pre + ".conv1.weight"], None, 1, 1)
-            o = F.prelu(_bn_train(sd, pre + ".bn2", o), sd[pre + ".prelu.weight"])
-            o = F.conv2d(o, sd[pre + ".conv2.weight"], None, stride, 1)
+            o = E.R(_bn_train(sd, pre + ".bn1", h))
+            o = conv(o, pre + ".conv1", 1, 1)
+            o = E.R(F.prelu(_bn_train(sd, pre + ".bn2", o), sd[pre + ".prelu.weight"]))
+            o = conv(o, pre + ".conv2", stride, 1)
             o = _bn_train(sd, pre + ".bn3", o)
             if bi == 0:
-                idn = F.conv2d(h, sd[pre + ".downsample.0.weight"], None, stride, 0)
-                idn = _bn_train(sd, pre + ".downsample.1", idn)
+                idn = conv(h, pre + ".downsample.0", stride, 0)
+                idn = E.R(_bn_train(sd, pre + ".downsample.1", idn))
             else:
                 idn = h
-            h = o + idn
-    h = _bn_train(sd, "bn2", h)
+            h = E.R(o + idn)
+    h = E.R(_bn_train(sd, "bn2", h))
     h = torch.flatten(h, 1)
-    h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
+    h = E.G(F.linear(h, E.W(sd["fc.weight"]), sd["fc.bias"]))
     h = _bn_train(sd, "features", h)
     return F.normalize(h)
 
 
-def mobilefacenet_forward(sd, x):
-    def convblock(name, h, stride, pad, dw=False, linear=False):
-        w = sd[name + ".conv.weight"]
-        h = F.conv2d(h, w, None, stride, pad, 1, w.shape[0] if dw else 1)
-        h = _bn_train(sd, name + ".bn", h)
-        return h if linear else F.prelu(h, sd[name + ".prelu.weight"])
+def mobilefacenet_forward(sd, x, emulate_bf16=False):
+    E = Emu(emulate_bf16)
 
-    h = convblock("conv1", x, 2, 1)
-    h = convblock("dw_conv1", h, 1, 1, dw=True)
+    def unit(h, wname, bn, prelu, stride, pad, dw=False, res=None):
+        """conv -> BN (-> PReLU) (+ residual), one executor unit: the convolution output and the unit output are bf16
+        tensors on the device; depthwise filters are used as fp32 (csrc/dw.hip), MFMA weights as bf16."""
+        w = sd[wname]
+        c = E.R(F.conv2d(E.G(h), w if dw else E.W(w), None, stride, pad, 1, w.shape[0] if dw else 1))
+        a = _bn_train(sd, bn, c)
+        if prelu is not None:
+            a = F.prelu(a, sd[prelu])
+        if res is not None:
+            a = a + res
+        return E.R(a)
+
+    h = unit(E.X(x), "conv1.conv.weight", "conv1.bn", "conv1.prelu.weight", 2, 1)
+    h = unit(h, "dw_conv1.conv.weight", "dw_conv1.bn", "dw_conv1.prelu.weight", 1, 1, dw=True)
     cur, bi = 64, 0
     for t, c, n, s in MOBILE_SETTING:
         for i in range(n):
             pre = "blocks.%d.conv" % bi
             stride = s if i == 0 else 1
-            o = F.conv2d(h, sd[pre + ".0.weight"])
-            o = F.prelu(_bn_train(sd, pre + ".1", o), sd[pre + ".2.weight"])
-            w = sd[pre + ".3.weight"]
-            o = F.conv2d(o, w, None, stride, 1, 1, w.shape[0])
-            o = F.prelu(_bn_train(sd, pre + ".4", o), sd[pre + ".5.weight"])
-            o = F.conv2d(o, sd[pre + ".6.weight"])
-            o = _bn_train(sd, pre + ".7", o)
-            h = h + o if (stride == 1 and cur == c) else o
+            o = unit(h, pre + ".0.weight", pre + ".1", pre + ".2.weight", 1, 0)
+            o = unit(o, pre + ".3.weight", pre + ".4", pre + ".5.weight", stride, 1, dw=True)
+            h = unit(o, pre + ".6.weight", pre + ".7", None, 1, 0, res=h if (stride == 1 and cur == c) else None)
             cur = c
             bi += 1
-    h = convblock("conv2", h, 1, 0)
-    h = convblock("linear7", h, 1, 0, dw=True, linear=True)
-    h = convblock("linear1", h, 1, 0, linear=True)
+    h = unit(h, "conv2.conv.weight", "conv2.bn", "conv2.prelu.weight", 1, 0)
+    h = unit(h, "linear7.conv.weight", "linear7.bn", None, 1, 0, dw=True)
+    # linear1: the 1x1 contraction runs on MFMA with an fp32 output; its BatchNorm and the normalisation stay fp32
+    h = E.G(F.conv2d(E.G(h), E.W(sd["linear1.conv.weight"])))
+    h = _bn_train(sd, "linear1.bn", h)
     return F.normalize(torch.flatten(h, 1))
 
 
-def make_backbone(net_type, feat_dim, gen=None, layers=None):
+def make_backbone(net_type, feat_dim, gen=None, layers=None, emulate_bf16=False):
     """Returns (state_dict, forward(sd, x))."""
     if net_type == "mobile":
-        return mobilefacenet_state(feat_dim, gen), mobilefacenet_forward
+        return mobilefacenet_state(feat_dim, gen), (lambda sd, x: mobilefacenet_forward(sd, x, emulate_bf16))
     lay = tuple(layers) if layers is not None else IRESNET_LAYERS[net_type]
-    return iresnet_state(lay, feat_dim, gen), (lambda sd, x: iresnet_forward(sd, x, lay))
+    return iresnet_state(lay, feat_dim, gen), (lambda sd, x: iresnet_forward(sd, x, lay, emulate_bf16))

@@ -108,9 +108,9 @@ class FFCRef(object):
     """Whole-step restatement: FFC.__init__ (ffc.py:11-55) + forward (ffc.py:264-267)."""
 
     def __init__(self, net_type, feat_dim, queue_size, scale=32.0, loss_type="AM", margin=0.4, momentum=0.99,
-                 gen=None, layers=None, dtype=torch.float32):
+                 gen=None, layers=None, dtype=torch.float32, emulate_bf16=False):
         assert loss_type in ("AM", "Arc", "SV")
-        self.probe, self.fwd = bb.make_backbone(net_type, feat_dim, gen, layers)
+        self.probe, self.fwd = bb.make_backbone(net_type, feat_dim, gen, layers, emulate_bf16)
         self.probe = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in self.probe.items()}
         for k, v in self.probe.items():
             if bb.trainable(k):
@@ -150,9 +150,9 @@ class FFCRef(object):
         return loss1 + loss2
 
 
-def sgd_nesterov_step_ref(params, grads, bufs, lr, momentum=0.9, weight_decay=1e-4):
-    """torch.optim.SGD(nesterov=True) update rule (reference optim/optimizer.py:148-150 builds it
-    from config/optim_config:9-13).  bufs[i] is None on the first step."""
+def sgd_nesterov_step_ref(params, grads, bufs, lr, momentum=0.9, weight_decay=1e-4, nesterov=True):
+    """torch.optim.SGD update rule with momentum and weight decay, nesterov by default (reference
+    optim/optimizer.py:148-150 builds it from config/optim_config:9-13).  bufs[i] is None on the first step."""
     with torch.no_grad():
         for i, (p, g) in enumerate(zip(params, grads)):
             d = g + weight_decay * p
@@ -160,5 +160,5 @@ def sgd_nesterov_step_ref(params, grads, bufs, lr, momentum=0.9, weight_decay=1e
                 bufs[i] = d.clone()
             else:
                 bufs[i].mul_(momentum).add_(d)
-            p.add_(d + momentum * bufs[i], alpha=-lr)
+            p.add_(d + momentum * bufs[i] if nesterov else bufs[i], alpha=-lr)
     return bufs

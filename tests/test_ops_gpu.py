@@ -260,3 +260,64 @@ def test_stem_im2col_stride2_matches_conv():
     d = ops.ConvDesc(N, H // 2, H // 2, 32, 64, 1, 1, 1, 0)
     y = ops.conv2d_fwd(cols, wb, d)
     close(y.permute(0, 3, 1, 2), bf(F.conv2d(bf(x), w, None, 2, 1)), 1e-2)
+
+
+# The extents the benchmark actually runs (SURVEY 8 a-conv: 112x112 / 56x56 feature maps of the 64-channel stages, the
+# 128 / 256 / 512-channel stages at their own resolution), batch >= 4, default kernel variant.
+TRUE_SHAPES = [(64, 64, 3, 1, 1, 112, 4), (64, 64, 3, 2, 1, 112, 4), (64, 64, 1, 2, 0, 112, 4), (64, 64, 3, 1, 1, 56, 4),
+               (64, 128, 3, 1, 1, 56, 4), (128, 128, 3, 2, 1, 56, 4), (64, 128, 1, 2, 0, 56, 4), (128, 128, 3, 1, 1, 28, 6),
+               (256, 256, 3, 2, 1, 28, 6), (256, 256, 3, 1, 1, 14, 8), (512, 512, 3, 2, 1, 14, 8), (512, 512, 3, 1, 1, 7, 8)]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw,N", TRUE_SHAPES)
+def test_conv_at_benchmarked_extents(cin, cout, k, stride, pad, hw, N):
+    from vlsfr_amd import ops
+    torch.manual_seed(cin + cout + k + stride + hw)
+    torch.set_num_threads(16)
+    x = bf(torch.randn(N, cin, hw, hw))
+    w = bf(torch.randn(cout, cin, k, k) * 0.05)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride, pad)
+    dy = bf(torch.randn_like(y_ref))
+    y_ref.backward(dy)
+    d = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad)
+    xg = nhwc(x).cuda().to(torch.bfloat16)
+    wb, wT = ops.cast_weight(w.permute(0, 2, 3, 1).contiguous().cuda(), cout, k * k, cin)
+    stats = ops.new_sums(cout, "cuda")
+    y = ops.conv2d_fwd(xg, wb, d, stats=stats)
+    close(y.permute(0, 3, 1, 2), bf(y_ref.detach()), 1e-2)
+    yf = y.float().reshape(-1, cout)
+    close(stats.sum(0)[0], yf.sum(0).cpu(), 1e-3)
+    close(stats.sum(0)[1], (yf * yf).sum(0).cpu(), 1e-3)
+    dyg = nhwc(dy).cuda().to(torch.bfloat16)
+    close(ops.conv2d_dgrad(dyg, wT, d).permute(0, 3, 1, 2), xr.grad, 1e-2)
+    close(ops.conv2d_wgrad(dyg, xg, d).permute(0, 3, 1, 2), wr.grad, 2e-3)
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw", [(64, 64, 3, 1, 56), (64, 64, 3, 2, 112), (256, 256, 3, 1, 14)])
+def test_conv_batch_256_equals_small_batch_kernel_on_slices(cin, cout, k, stride, hw):
+    """Size-independent property at the benchmark's batch_size 256: a convolution is independent per image, so every
+    4-image slice of the batch-256 forward / input-gradient result must EQUAL (bit for bit: same k order) what the
+    batch-4 launch computes for those images, and the batch-256 weight gradient must be the sum of the 64 slice
+    gradients (fp32 atomics: summation order only)."""
+    from vlsfr_amd import ops
+    torch.manual_seed(hw + cin)
+    N, n = 256, 4
+    pad = 1
+    ho = (hw + 2 * pad - k) // stride + 1
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16)
+    dy = torch.randn(N, ho, ho, cout, device="cuda", generator=gen).to(torch.bfloat16)
+    w = (torch.randn(cout, k, k, cin, device="cuda", generator=gen) * 0.05).contiguous()
+    wb, wT = ops.cast_weight(w, cout, k * k, cin)
+    big, small = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad), ops.ConvDesc(n, hw, hw, cin, cout, k, k, stride, pad)
+    y = ops.conv2d_fwd(x, wb, big)
+    dx = ops.conv2d_dgrad(dy, wT, big)
+    dw = ops.conv2d_wgrad(dy, x, big)
+    dw_sum = torch.zeros_like(dw, dtype=torch.float64)
+    for s0 in (0, 124, 252):
+        assert torch.equal(ops.conv2d_fwd(x[s0:s0 + n].contiguous(), wb, small), y[s0:s0 + n])
+        assert torch.equal(ops.conv2d_dgrad(dy[s0:s0 + n].contiguous(), wT, small), dx[s0:s0 + n])
+    for s0 in range(0, N, n):
+        dw_sum += ops.conv2d_wgrad(dy[s0:s0 + n].contiguous(), x[s0:s0 + n].contiguous(), small).double()
+    close(dw, dw_sum.float().cpu(), 1e-3)

@@ -18,6 +18,7 @@
 //   are read back with ds_read_b64_tr_b16 (hardware transpose).  Split over the pixel range with
 //   fp32 atomics into the (pre-zeroed or accumulating) gradient buffer.
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -26,20 +27,36 @@
 using namespace vlsfr;
 
 namespace vlsfr {
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around every launch of
+// a kernel family while profiling is enabled (ProfScope is declared in hip_common.h; head.hip uses it too).
+struct ProfRec {
+  hipEvent_t a, b;
+  double work;
+  int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;   // forward and backward passes are enqueued from different host threads
+ProfScope::ProfScope(hipStream_t s, int fam, double w) : st(s), on(g_prof_on), family(fam), work(w) {
+  if (!on) return;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+    on = false;
+    return;
+  }
+  (void)hipEventRecord(a, st);
+}
+ProfScope::~ProfScope() {
+  if (!on) return;
+  (void)hipEventRecord(b, st);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(ProfRec{a, b, work, family});
+}
 extern int g_dw_wgrad_blocks;   // csrc/dw.hip
 int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
 
 namespace {
 
-// ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around
-// every launch of one kernel family while profiling is enabled.
-struct ProfRec {
-  hipEvent_t a, b;
-  double flops;
-  int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad
-};
-bool g_prof_on = false;
 // vlsfr_set_option switches (A/B and diagnostics; the defaults are what the measurements in DESIGN.md section 8 chose)
 #define VLSFR_DEFAULT_CONV_VARIANT 3
 int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // "conv_glds": 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4,
@@ -52,28 +69,6 @@ int g_wgrad_target = 384;    // "wgrad_target_wgs": workgroups the pixel range o
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
-std::vector<ProfRec> g_prof;
-
-struct ProfScope {
-  hipStream_t st;
-  bool on;
-  ProfRec r;
-  ProfScope(hipStream_t s, int family, double flops) : st(s), on(g_prof_on) {
-    if (!on) return;
-    r.family = family;
-    r.flops = flops;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
-      on = false;
-      return;
-    }
-    hipEventRecord(r.a, st);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    hipEventRecord(r.b, st);
-    g_prof.push_back(r);
-  }
-};
 
 struct ConvArgs {
   const u16* x;      // gathered activations [Nimg, H, W, C] bf16
@@ -1393,7 +1388,7 @@ int run_igemm(ConvArgs a, hipStream_t st) {
 
 extern "C" {
 
-void vlsfr_profile_enable(int32_t on) { g_prof_on = on != 0; }
+void vlsfr_profile_enable(int32_t on) { vlsfr::g_prof_on = on != 0; }
 
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "conv_glds")) {
@@ -1445,7 +1440,7 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
   if (!total_ms || !total_flops || !launches) return fail(VLSFR_EINVAL, "vlsfr_profile_collect: null argument");
   double ms = 0, fl = 0;
   int64_t n = 0;
-  for (auto& r : g_prof) {
+  for (auto& r : vlsfr::g_prof) {
     if (r.family != family) continue;
     hipError_t e = hipEventSynchronize(r.b);
     if (e != hipSuccess) return hip_fail(e, "vlsfr_profile_collect: hipEventSynchronize");
@@ -1453,7 +1448,7 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
     e = hipEventElapsedTime(&t, r.a, r.b);
     if (e != hipSuccess) return hip_fail(e, "vlsfr_profile_collect: hipEventElapsedTime");
     ms += t;
-    fl += r.flops;
+    fl += r.work;
     ++n;
   }
   *total_ms = ms;
@@ -1463,11 +1458,11 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
 }
 
 void vlsfr_profile_reset(void) {
-  for (auto& r : g_prof) {
-    hipEventDestroy(r.a);
-    hipEventDestroy(r.b);
+  for (auto& r : vlsfr::g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
   }
-  g_prof.clear();
+  vlsfr::g_prof.clear();
 }
 
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk, int32_t out_f32,

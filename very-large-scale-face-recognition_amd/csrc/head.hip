@@ -1117,6 +1117,9 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
     a.sv_thr = sv ? thr + (size_t)set * pl.Bp : nullptr;
     const bool topk = want_topk && set == 0;   // top-k uses raw cosines: variant independent
     int rc;
+    // bench.py's roofline leg (family 2): both contractions of the sweep, 4 B Q D FLOPs (count only
+    // contractions actually executed)
+    ProfScope prof(st, 2, 4.0 * (double)a.B * (double)a.Q * (double)a.D);
     if (pl.fast) {
       Sweep16Args f;
       f.p = a.p;

@@ -92,6 +92,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Per-launch timing of a kernel family while vlsfr_profile_enable(1) is in effect (include/vlsfr.h section 9):
+// HIP events on the launch stream before and after the scope.  `work` = algorithmic FLOPs of the launch.
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  hipEvent_t a, b;
+  int family;
+  double work;
+  ProfScope(hipStream_t s, int family, double work);
+  ~ProfScope();
+};
+
 inline int hip_fail(hipError_t e, const char* what) {
   return fail(VLSFR_EHIP, "%s: %s", what, hipGetErrorString(e));
 }

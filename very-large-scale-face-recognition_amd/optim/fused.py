@@ -28,6 +28,8 @@ def _chunk_table(groups):
         if not _dense_same_layout(ts):
             raise _lib.VlsfrError("fused sweep: tensors of one group must be fp32, dense and share strides")
         n = ts[0].numel()
+        if any(t.data_ptr() % 16 for t in ts):
+            raise _lib.VlsfrError("fused sweep: tensor storage must be 16-byte aligned")
         for off in range(0, n, CHUNK):
             rows.append([t.data_ptr() + 4 * off for t in ts] + [min(CHUNK, n - off)])
     return np.asarray(rows, dtype=np.int64).reshape(len(rows), len(groups[0]) + 1 if groups else 1)
@@ -82,7 +84,8 @@ class FusedSGD(torch.optim.Optimizer):
         ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
         if not ps or not ps[0].is_cuda:
             return None
-        total = sum(p.numel() for p in ps)
+        pad4 = lambda n: (n + 3) & ~3          # every view starts 16-byte aligned: the sweeps use 16-byte accesses
+        total = sum(pad4(p.numel()) for p in ps)
         flat = torch.zeros(total, dtype=torch.float32, device=ps[0].device)
         off = 0
         for p in ps:
@@ -92,7 +95,7 @@ class FusedSGD(torch.optim.Optimizer):
             if p.grad is not None:
                 view.copy_(p.grad)
             p.grad = view
-            off += p.numel()
+            off += pad4(p.numel())             # the padding stays zero (harmless in an all-reduce)
         self._flat_grad = flat
         self._flat_key = tuple(p.grad.data_ptr() for p in ps)
         return flat
