@@ -246,8 +246,51 @@ def step_vectors():
         print(tag, "loss", float(loss))
 
 
+SCHED_CONFIGS = [
+    dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
+         milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1]),                                   # config/optim_config
+    dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=2, epochs=20,
+         milestones=[8, 14, 17], gammas=[0.1, 0.5, 0.1]),
+    dict(optim="SGD", scheduler="cos", LR=0.05, momentum=0.9, decay=1e-4, nesterov=True, warmup=3, epochs=18, eta_min=1e-5),
+    dict(optim="SGD", scheduler="exponential", LR=0.2, momentum=0.9, decay=1e-4, nesterov=True, warmup=1, epochs=12, gamma=0.9),
+    dict(optim="SGD", scheduler="linear", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=2, epochs=25, LR_min=1e-4),
+]
+
+
+def scheduler_vectors():
+    """lr(epoch, iter) of the reference's four warm-up schedules (optim/optimizer.py:47-128) through its own factory
+    (:142-168) on a grid of the two update calls main.py makes: update(None, it / len) per iteration (main.py:39-40)
+    and update(epoch, 0.0) per epoch (main.py:138-139)."""
+    import contextlib
+    import io
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_optimizer", "/root/reference/optim/optimizer.py")
+    ref_opt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_opt)
+    out = []
+    for cfg in SCHED_CONFIGS:
+        p = [torch.nn.Parameter(torch.zeros(2))]
+        with contextlib.redirect_stdout(io.StringIO()):            # CosineAnnealingLR.get_lr prints (SURVEY F12)
+            opt, sch = ref_opt.get_optim_scheduler(p, cfg)
+            rows = []
+            for epoch in range(0, cfg["epochs"] + cfg["warmup"] + 3):
+                sch.update(epoch, 0.0)
+                rows.append([epoch, 0.0, opt.param_groups[0]["lr"]])
+                for it in (0.25, 0.5, 0.875):
+                    sch.update(None, it)
+                    rows.append([epoch, it, opt.param_groups[0]["lr"]])
+        out.append(dict(config=cfg, rows=rows))
+    with open(os.path.join(HERE, "scheduler_lrs.json"), "w") as f:
+        json.dump(out, f)
+    print("scheduler_lrs.json: %d configs, %d points" % (len(out), sum(len(o["rows"]) for o in out)))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "schedulers":
+        scheduler_vectors()
+        sys.exit(0)
+    scheduler_vectors()
     lru_traces()
     head_vectors()
     step_vectors()

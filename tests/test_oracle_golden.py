@@ -148,3 +148,22 @@ def test_step_oracle_matches_reference(tag):
     assert [k for k, _ in o.lru.state_dict()] == z["lru_final_keys"].tolist()
     assert [v for _, v in o.lru.state_dict()] == z["lru_final_slots"].tolist()
     assert o.qp == z["qp_final"].astype(int).tolist()
+
+
+def test_schedulers_match_reference_values():
+    """The warm-up learning-rate schedules (optim/optimizer.py:47-128 through the factory :142-168) against lr values
+    generated by the reference itself (tests/golden/make_golden.py scheduler_vectors): multistep, cosine, exponential
+    and linear, with warm-up, on the grid of update(epoch, 0.0) / update(None, iter) calls main.py makes."""
+    import json
+    from vlsfr_amd.optim import get_optim_scheduler
+    with open(os.path.join(G, "scheduler_lrs.json")) as f:
+        cases = json.load(f)
+    assert {c["config"]["scheduler"] for c in cases} == {"multistep", "cos", "exponential", "linear"}
+    for case in cases:
+        opt, sch = get_optim_scheduler([torch.nn.Parameter(torch.zeros(2))], case["config"])
+        for epoch, it, lr in case["rows"]:
+            if it == 0.0:
+                sch.update(int(epoch), 0.0)
+            else:
+                sch.update(None, float(it))
+            assert abs(opt.param_groups[0]["lr"] - lr) <= 1e-12 * max(1.0, abs(lr)), (case["config"]["scheduler"], epoch, it)

@@ -345,3 +345,43 @@ def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
     for k, v in o.gallery.items():
         if not bb.is_buffer(k):
             np.testing.assert_allclose(gp[k].detach().cpu().numpy(), v.float().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_reference_loop_shape_with_autocast_and_gradscaler():
+    """The reference's loop (main.py:64-71,133): `with torch.amp.autocast('cuda')` around the forward,
+    `scaler.scale(loss).backward(); scaler.step(optimizer); scaler.update()`.  The MI355X path needs neither (bf16
+    operands have fp32's exponent range) — leaving them in must be harmless: same loss, same updated parameters (the
+    loss scale is a power of two: scaling and unscaling are exact; what remains is the run-to-run noise of the atomic
+    summation order, measured here by a second plain run), same pool and allocator state."""
+    from vlsfr_amd.optim import get_optim_scheduler
+    z = np.load(os.path.join(G, "step_irtiny.npz"))
+    cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
+               milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])
+    outs = []
+    for mode in ("plain", "plain", "amp"):
+        m, x, y, xl, yl = build_ffc(z, "irtiny")
+        opt, sched = get_optim_scheduler([p for p in m.parameters() if p.requires_grad], cfg)
+        sched.update(None, 0.0)
+        opt.zero_grad()
+        if mode == "amp":
+            scaler = torch.amp.GradScaler("cuda")
+            with torch.amp.autocast("cuda"):
+                loss = m(x, y, xl, yl)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            assert scaler.get_scale() == 65536.0          # no inf / nan was found: the step was taken
+        else:
+            loss = m(x, y, xl, yl)
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        assert loss.dtype == torch.float32
+        outs.append((float(loss.detach()), np.concatenate([p.detach().float().cpu().numpy().ravel() for p in m.probe_net.parameters()]),
+                     m.queue.clone(), m.lru.state_dict(), m._state().qp.copy()))
+    (l0, w0, q0, s0, qp0), (l1, w1, _, _, _), (l2, w2, q2, s2, qp2) = outs
+    noise_l, noise_w = abs(l0 - l1) / abs(l0), rel_l2(w1, w0)
+    assert abs(l0 - l2) / abs(l0) <= max(4 * noise_l, 1e-3)
+    assert rel_l2(w2, w0) <= max(4 * noise_w, 1e-4)
+    assert s0 == s2 and (qp0 == qp2).all()
+    assert float((q0 - q2).abs().max()) <= 5e-3
