@@ -179,11 +179,17 @@ def main():
     note("pool %d slots on device (%.1f GB), LRU restored" % (Q, model.queue.numel() * 4 / 1e9))
     cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
                milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])     # config/optim_config
-    opt, sched = get_optim_scheduler([p for p in model.parameters() if p.requires_grad], cfg)
-    sched.update(0, 0.0)
     step_model = model
     if world > 1:
+        # N > 1: partitioned SGD (each rank updates 1/N of the parameters; gradients reduce-scattered bucket by bucket
+        # under the backward pass), behind the reference's scheduler interface
+        from vlsfr_amd.optim.optimizer import WarmupSchedule
         step_model = ShardedFFC(model, dist) if sharded else DataParallelFFC(model, dist)
+        opt = step_model.make_optimizer(cfg["LR"], cfg["momentum"], cfg["decay"], cfg["nesterov"])
+        sched = WarmupSchedule(opt, "multistep", cfg["warmup"], cfg["epochs"], milestones=cfg["milestones"], gammas=cfg["gammas"])
+    else:
+        opt, sched = get_optim_scheduler([p for p in model.parameters() if p.requires_grad], cfg)
+    sched.update(0, 0.0)
     rng = np.random.default_rng(1234 + rank)
     B = args.batch
     batches = [synth_batch(rng, B, args.identities, dev) for _ in range(min(4, args.steps + args.warmup))]
@@ -266,6 +272,7 @@ def main():
         fams = collect()
         model.__dict__['concurrent_streams'] = True
         model.probe_net.concurrent_backward = True
+    loss_val = float(step_model.global_loss(loss)) if world > 1 else float(loss.detach())   # collective: every rank
     if rank != 0:
         return
     dom = max(fams, key=lambda k: fams[k][0])
@@ -313,7 +320,8 @@ def main():
         "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
                                "(2 x %d faces per step per GPU), SGD-nesterov, 112x112 synthetic images" %
                                (args.net, args.identities, Q, args.feat, args.loss, B, B),
-                   "parallelism": ("dp%d" % world) + ("" if world == 1 else "+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")), "loss": float(loss.detach())},
+                   "parallelism": ("dp%d" % world) + ("" if world == 1 else "+zero1-sgd+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")),
+                   "loss": loss_val},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -325,6 +325,13 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
                           void* stream);
 int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const float* const* params,
                            float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
+/* The same pass, signalling when groups of parameter gradients are complete, so that a multi-GPU caller can
+ * start reducing them while the rest of the backward pass still runs (parallel.py): stage_events (or NULL) is an
+ * array of 5 events (vlsfr_event_create; entries may be NULL) recorded on `stream` in backward order —
+ * [0] bn2 / fc / features, [1] layer4, [2] layer3, [3] layer2, [4] layer1 + stem. */
+int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, const float* const* params,
+                                  float* const* grads, const void* wcache, void* ctx, void* scratch,
+                                  void* const* stage_events, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7b. MobileFaceNet backbone executor: same contract as section 7 for reference
@@ -376,6 +383,16 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
  * the ping-pong convolution variant (scripts/conv_trace.py); nullptr switches the stamps off. */
 int vlsfr_conv_trace(void* device_buffer);
 void vlsfr_profile_reset(void);
+
+/* ------------------------------------------------------------------------------------------
+ * 10. Stream ordering helpers (HIP events without timing) for callers that spread the step over several
+ *     streams: the multi-GPU step waits on the per-stage events of vlsfr_iresnet_backward_staged from its
+ *     communication stream.  The reference has no counterpart (single default stream).
+ * ---------------------------------------------------------------------------------------- */
+int vlsfr_event_create(void** event);
+void vlsfr_event_destroy(void* event);
+int vlsfr_event_record(void* event, void* stream);
+int vlsfr_stream_wait_event(void* stream, void* event);
 
 #ifdef __cplusplus
 }

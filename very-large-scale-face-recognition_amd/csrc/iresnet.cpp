@@ -379,8 +379,21 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
 
 int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const float* const* params, float* const* grads,
                            const void* wcache, void* ctx_v, void* scratch, void* st) {
+  return vlsfr_iresnet_backward_staged(n, demb, params, grads, wcache, ctx_v, scratch, nullptr, st);
+}
+
+int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, const float* const* params,
+                                  float* const* grads, const void* wcache, void* ctx_v, void* scratch,
+                                  void* const* stage_events, void* st) {
   if (!n || !demb || !params || !grads || !wcache || !ctx_v || !scratch)
     return fail(VLSFR_EINVAL, "vlsfr_iresnet_backward: null argument");
+  // stage_events[k] is recorded on the stream once every parameter gradient of bucket k has been enqueued:
+  // 0 = tail (bn2, fc, features), 1..3 = layer4..layer2, 4 = layer1 + stem (backward order)
+  auto signal = [&](int k) -> int {
+    if (!stage_events || !stage_events[k]) return VLSFR_OK;
+    hipError_t ee = hipEventRecord((hipEvent_t)stage_events[k], (hipStream_t)st);
+    return ee == hipSuccess ? VLSFR_OK : fail(VLSFR_EHIP, "vlsfr_iresnet_backward: hipEventRecord: %s", hipGetErrorString(ee));
+  };
   char* ctx = (char*)ctx_v;
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
@@ -399,8 +412,10 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
   char* dcur = sc.g[1];
   RUN(bn_backward(n->bn_last, dflat, ctx + last.out, dcur, (int64_t)B * HWl, HWl, nullptr, 1, params, grads, ctx,
                   st));
+  RUN(signal(0));
   // blocks in reverse; dcur rotates through the three gradient buffers
   int cur_i = 1;
+  int stage = 4, left = n->layers[3];   // blocks of the current stage still to go
   for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
     const Block& b = n->blocks[k];
     const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
@@ -425,6 +440,11 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
     // d x_in = bn1 backward of d a1, plus the shortcut gradient
     RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st));
     cur_i = (cur_i + 1) % 3;   // t1 is the new dcur
+    if (--left == 0 && stage > 1) {   // stage 4, 3, 2 complete -> buckets 1, 2, 3 (stage 1 goes with the stem)
+      RUN(signal(5 - stage));
+      --stage;
+      left = n->layers[stage - 1];
+    }
   }
   // stem
   char* dc0 = sc.g[(cur_i + 1) % 3];
@@ -433,7 +453,8 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
   hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e));
   RUN(vlsfr_conv2d_wgrad(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, st));
-  return vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, st);
+  RUN(vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, st));
+  return signal(4);
 }
 
 }  // extern "C"

@@ -315,8 +315,11 @@ class ShardedDcpHead(object):
             st["thr"] = comm.all_reduce_max(st["thr"])
         return self.sweep(st)
 
-    def combine(self, st, comm):
-        """comm: all_reduce_max(t), all_reduce_sum(t), all_gather(t) -> [world, ...] (in place / returned)."""
+    def combine(self, st, comm, own_rows=None):
+        """comm: all_reduce_max(t), all_gather(t) -> [world, ...], and all_reduce_sum(t) or — with own_rows = (r0, r1),
+        the rows of the gathered batch this rank's probe images produced — reduce_scatter_rows(t): the packed
+        softmax state is then summed straight into its owner, and finish() yields the loss share and dL/dp of those
+        rows only (half the bytes of the all-reduce, 1/W of the finish work)."""
         B, k = st["M"].shape[0], self.hard_neg
         plan = st["plan"]
         n_out = B - plan.n_pos
@@ -348,19 +351,27 @@ class ShardedDcpHead(object):
                           _stream_ptr()), "vlsfr_head_outlier_accum")
             st["_keep"] = (col_c, w_c)
         packed = torch.cat([st["O"] * w.unsqueeze(2), st["T"], (st["L"] * w).unsqueeze(2), st["zt"].unsqueeze(2)], dim=2)
-        packed = comm.all_reduce_sum(packed.contiguous())
-        st.update(Mg=M, packed=packed, sel_loss=sel_loss)
+        if own_rows is None:
+            packed = comm.all_reduce_sum(packed.contiguous())
+            own_rows = (0, B)
+        else:
+            packed = comm.reduce_scatter_rows(packed.contiguous())
+        st.update(Mg=M, packed=packed, sel_loss=sel_loss, rows=own_rows)
         return st
 
     def finish(self, st):
-        """Loss (identical on every rank) and dL/dp for all rows of the batch."""
+        """Loss and dL/dp of the rows combine() left on this rank: all rows of the batch (all-reduce form: the loss is
+        then identical on every rank), or this rank's own rows (reduce-scatter form: the losses of the ranks sum to
+        the reference loss)."""
         D, plan = self.D, st["plan"]
+        r0, r1 = st.get("rows", (0, int(st["M"].shape[0])))
         O, T = st["packed"][:, :, :D], st["packed"][:, :, D:2 * D]
         Lg, zt = st["packed"][:, :, 2 * D], st["packed"][:, :, 2 * D + 1]
-        pos = (st["label"] >= 0).view(-1, 1)
+        pos = (st["label"][r0:r1] >= 0).view(-1, 1)
         inv_pos = 1.0 / max(plan.n_pos, 1)
         safe_L = torch.where(pos, Lg, torch.ones_like(Lg))
-        row_loss = torch.where(pos, (0.6931471805599453 * (st["Mg"] + torch.log2(safe_L)) - zt) * inv_pos, st["sel_loss"])
+        row_loss = torch.where(pos, (0.6931471805599453 * (st["Mg"][r0:r1] + torch.log2(safe_L)) - zt) * inv_pos,
+                               st["sel_loss"][r0:r1])
         dP = torch.where(pos.unsqueeze(2), self.scale * inv_pos * O / safe_L.unsqueeze(2) + T, T).sum(1)
         if not st["transactional"]:
             sc = self.L.vlsfr_pool_scatter

@@ -173,6 +173,14 @@ class LRU(object):
         """`state_dict` as (int64 keys, int32 slots) arrays, MRU -> LRU."""
         return self._state_arrays()
 
+    def reset(self):
+        """Back to the state of a freshly constructed LRU(capacity) (the reference's clear() keeps cur_idx, so a used
+        allocator cannot take restore(); loading a checkpoint into a live run needs this)."""
+        self._L.vlsfr_lru_destroy(self._h)
+        h = ctypes.c_void_p()
+        _lib.check(self._L.vlsfr_lru_create(int(self.capacity), ctypes.byref(h)), "vlsfr_lru_create")
+        self._h.value = h.value
+
     # lru.py:132-141
     def clear(self):
         _lib.check(self._L.vlsfr_lru_clear(self._h), "vlsfr_lru_clear")

@@ -65,7 +65,7 @@ def save_checkpoint(path, ffc_net, pool, optimizer=None, real_iter=0):
     """The reference's dictionary (main.py:85: state_dict / lru / fc / qp) plus one extra key, `resume`, with what
     the reference does not save but an exact continuation needs (EMA'd gallery weights, optimizer momenta)."""
     torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict(),
-                'fc': pool.cpu(), 'qp': ffc_net.queue_position_dict.to_dict(),
+                'fc': pool.cpu() if pool is not None else None, 'qp': ffc_net.queue_position_dict.to_dict(),
                 'resume': {'gallery_state_dict': ffc_net.gallery_net.state_dict(), 'real_iter': int(real_iter),
                            'optimizer': optimizer.state_dict() if optimizer is not None else None}}, path)
 
@@ -81,7 +81,7 @@ def load_checkpoint(path, ffc_net, optimizer=None):
     with torch.no_grad():
         ffc_net.queue.copy_(ck['fc'].to(ffc_net.queue.device))
     state = ffc_net._state()
-    state.lru.clear()
+    state.lru.reset()
     state.lru.restore([tuple(kv) for kv in ck['lru']])
     qp = ck['qp']
     state.qp[:] = np.asarray([qp[i] for i in range(len(qp))], dtype=np.uint8)
@@ -122,12 +122,20 @@ def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_
             if lr_policy == 'ReduceLROnPlateau':
                 lr_scheduler.step(loss_val)
             start = time.time()
-            # the sharded pool is gathered by every rank (a collective), rank 0 writes the file
-            pool = step_model.gather_pool() if hasattr(step_model, 'gather_pool') else ffc_net.queue
-            if conf.saved_dir and (world == 1 or torch.distributed.get_rank() == 0):
+            tag = real_iter // conf.print_freq
+            if hasattr(step_model, 'pool_state'):
+                # sharded pool: every rank writes ITS slots (no rank ever holds the whole pool: 410 GB at 100 M
+                # identities), rank 0 the model / allocator file with fc = None
+                if hasattr(optimizer, 'consolidate_state'):
+                    optimizer.consolidate_state()                                  # collective
+                if conf.saved_dir:
+                    os.makedirs(conf.saved_dir, exist_ok=True)
+                    torch.save(step_model.pool_state(), os.path.join(conf.saved_dir, '%d.pool%d.pt' % (tag, step_model.rank)))
+                    if step_model.rank == 0:
+                        save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % tag), ffc_net, None, optimizer, real_iter)
+            elif conf.saved_dir and (world == 1 or torch.distributed.get_rank() == 0):
                 os.makedirs(conf.saved_dir, exist_ok=True)
-                save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % (real_iter // conf.print_freq)), ffc_net, pool,
-                                optimizer, real_iter)
+                save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % tag), ffc_net, ffc_net.queue, optimizer, real_iter)
     return real_iter, loss
 
 
@@ -144,15 +152,36 @@ def train(conf, log=print):
     ffc_net = FFC(conf.net_type, conf.feat_dim, conf.queue_size, conf.scale, conf.loss_type, conf.margin, conf.alpha,
                   conf.neg_margin, conf.pretrained_model_path, conf.num_class).cuda()          # main.py:116-117
     optim_config = load_config(conf.optim_config) if conf.optim_config else dict(OPTIM_CONFIG)
-    optim, lr_scheduler = get_optim_scheduler([p for p in ffc_net.parameters() if p.requires_grad], optim_config)
-    start_iter = 0
-    if getattr(conf, "resume", ""):
-        start_iter = load_checkpoint(conf.resume, ffc_net, optim)      # before the pool is sharded over the ranks
     step_model = ffc_net
+    start_iter = 0
     if world > 1:
+        # one process per GPU: identity-sharded pool + partitioned SGD (parallel.py); the scheduler keeps the
+        # reference's interface around the partitioned optimizer
         from .parallel import DataParallelFFC, ShardedFFC
+        from .optim.optimizer import WarmupSchedule
+        if getattr(conf, "resume", ""):
+            start_iter = load_checkpoint(conf.resume, ffc_net, None)   # before the pool is sharded over the ranks
         sharded = conf.queue_size % world == 0
         step_model = ShardedFFC(ffc_net, dist) if sharded else DataParallelFFC(ffc_net, dist)
+        if optim_config['optim'] != 'SGD' or optim_config['scheduler'] == 'ReduceLROnPlateau':
+            raise ValueError("multi-GPU runs use the partitioned SGD with a warm-up schedule")
+        optim = step_model.make_optimizer(optim_config['LR'], optim_config['momentum'], optim_config['decay'],
+                                          optim_config['nesterov'])
+        hyper = {k: optim_config[k] for k in ('milestones', 'gammas', 'eta_min', 'gamma') if k in optim_config}
+        if optim_config['scheduler'] == 'cos':
+            hyper = dict(T_max=optim_config['epochs'], eta_min=optim_config['eta_min'])
+        elif optim_config['scheduler'] == 'linear':
+            hyper = dict(max_LR=optim_config['LR'], min_LR=optim_config['LR_min'])
+        elif optim_config['scheduler'] == 'multistep':
+            hyper = dict(milestones=optim_config['milestones'], gammas=optim_config['gammas'])
+        elif optim_config['scheduler'] == 'exponential':
+            hyper = dict(gamma=optim_config['gamma'])
+        lr_scheduler = WarmupSchedule(optim, optim_config['scheduler'], optim_config.get('warmup', 0),
+                                      optim_config.get('epochs', 1), **hyper)
+    else:
+        optim, lr_scheduler = get_optim_scheduler([p for p in ffc_net.parameters() if p.requires_grad], optim_config)
+        if getattr(conf, "resume", ""):
+            start_iter = load_checkpoint(conf.resume, ffc_net, optim)
     rank = dist.get_rank() if dist else 0
     real_iter, loss = start_iter, None
     for epoch in range(optim_config['epochs']):                                    # main.py:134-140

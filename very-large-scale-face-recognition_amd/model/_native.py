@@ -46,7 +46,7 @@ class _BackboneFn(torch.autograd.Function):
             net._ensure_grads()                         # allocate / zero missing .grad on the main stream
             side.wait_stream(main)                      # demb and everything before it
             with torch.cuda.stream(side):
-                net._run_backward(demb, ctx.ws, ctx.B, alt=True)
+                net._run_backward(demb, ctx.ws, ctx.B, alt=True, slot=1)
             demb.record_stream(side)
             ctx.ws.record_stream(side)
             if not net._join_queued:
@@ -57,7 +57,7 @@ class _BackboneFn(torch.autograd.Function):
                     torch.cuda.current_stream().wait_stream(side)
                 torch.autograd.Variable._execution_engine.queue_callback(join)
         else:
-            net._run_backward(demb, ctx.ws, ctx.B)
+            net._run_backward(demb, ctx.ws, ctx.B, slot=ctx.slot)
         ctx.ws = None
         return (None, None) + (None,) * len(net._plist)
 
@@ -222,7 +222,28 @@ class NativeBackbone(nn.Module):
             grads.append(p.grad)
         return grads
 
-    def _run_backward(self, demb, ws, B, alt=False):
+    # ---- gradient buckets for the multi-GPU step (parallel.py): parameter groups whose gradients are complete at
+    # the same point of the backward pass, in backward order; a subclass with a staged executor overrides both.
+    N_BUCKETS = 1
+
+    def bucket_of(self, name):
+        return 0
+
+    def stage_events(self, slot):
+        """Events of backward pass `slot` (0 / 1: the two passes of an FFC step), one per bucket, created on first use;
+        the pass records event k on ITS stream when bucket k's gradients are enqueued."""
+        evs = self.__dict__.setdefault("_stage_events", {})
+        if slot not in evs:
+            L = _lib.lib()
+            arr = (ctypes.c_void_p * self.N_BUCKETS)()
+            for k in range(self.N_BUCKETS):
+                e = ctypes.c_void_p()
+                _lib.check(L.vlsfr_event_create(ctypes.byref(e)), "vlsfr_event_create")
+                arr[k] = e.value
+            evs[slot] = arr
+        return evs[slot]
+
+    def _run_backward(self, demb, ws, B, alt=False, slot=0):
         L = _lib.lib()
         h, sizes = self._handle(B, demb.device)
         scratch = self._scratch
@@ -232,11 +253,22 @@ class NativeBackbone(nn.Module):
             scratch = self._scratch_alt
         params, _ = self._tables()
         grads = self._ensure_grads()
+        signal = self.__dict__.get("signal_stages", False)      # set by parallel.py: somebody waits on the events
+        staged = getattr(L, self._cprefix + "_backward_staged", None) if signal and self.N_BUCKETS > 1 else None
+        if staged is not None:
+            staged.restype = ctypes.c_int
+            _lib.check(staged(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
+                              ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                              ctypes.c_void_p(scratch.data_ptr()), self.stage_events(slot), _stream()),
+                       self._cprefix + "_backward_staged")
+            return
         bwd = getattr(L, self._cprefix + "_backward")
         bwd.restype = ctypes.c_int
         _lib.check(bwd(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
                        ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
                        ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward")
+        if signal:                                              # single bucket: complete when the pass is
+            _lib.check(L.vlsfr_event_record(ctypes.c_void_p(self.stage_events(slot)[0]), _stream()), "vlsfr_event_record")
 
     def forward(self, x):
         # Training mode always (the reference never calls .eval(), ffc.py:22-23); eval() only stops

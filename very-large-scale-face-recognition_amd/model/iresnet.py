@@ -76,6 +76,14 @@ class IResNet(NativeBackbone):
             layers.append(IBasicBlock(planes, planes))
         return nn.Sequential(*layers)
 
+    # gradient buckets in backward order (csrc/iresnet.cpp vlsfr_iresnet_backward_staged)
+    N_BUCKETS = 5
+    _BUCKET = {"bn2": 0, "fc": 0, "features": 0, "layer4": 1, "layer3": 2, "layer2": 3, "layer1": 4, "conv1": 4,
+               "bn1": 4, "prelu": 4}
+
+    def bucket_of(self, name):
+        return self._BUCKET[name.split(".")[0]]
+
     def _create(self, L, B, h):
         lay = (ctypes.c_int32 * 4)(*self.layers_cfg)
         L.vlsfr_iresnet_create.restype = ctypes.c_int

@@ -156,3 +156,145 @@ class FusedSGD(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is not None:
                     p.grad.zero_()
+
+
+class PartitionedSGD(FusedSGD):
+    """SGD-nesterov with the optimizer state and the update partitioned over the ranks of a node (ZeRO-1; the
+    "partitioned SGD" BASELINE.json's north_star adds to the reference's torch.optim.SGD, optim/optimizer.py:148-150).
+
+    Parameters and gradients live in two flat fp32 buffers with one layout: buckets (groups of parameters whose
+    gradients complete together in the backward pass, backward order), every parameter view 16-byte aligned, every
+    bucket padded to a multiple of 4 * world elements.  Per bucket and step:
+        reduce_bucket(b)   reduce-scatter(sum) of the bucket's gradients -> this rank's 1/world slice   [RCCL]
+        step()             fused update (csrc/optim.hip) of the rank's parameter slice against its momentum slice,
+                           then all-gather of the updated slices into every rank's flat parameter buffer     [RCCL]
+    Elementwise the update is torch.optim.SGD's, so the result equals the replicated FusedSGD on summed gradients
+    (tests/test_parallel_cpu.py runs both over gloo).  Momentum memory is 1/world per rank."""
+
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, nesterov=False, comm=None, bucket_of=None,
+                 n_buckets=1):
+        params = list(params)
+        super(PartitionedSGD, self).__init__(params, lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov)
+        self.comm = comm
+        self.world, self.rank = comm.world, comm.rank
+        self.n_buckets = int(n_buckets)
+        self._bucket_of = bucket_of or (lambda p: 0)
+        self._part = None
+
+    # ------------------------------------------------------------------------------------------
+    def _params(self):
+        return [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+
+    def partition(self):
+        """Builds the flat buffers (once, when the parameters are on their device) and re-points p.data / p.grad."""
+        if self._part is not None:
+            return self._part
+        ps = self._params()
+        dev = ps[0].device
+        pad4 = lambda n: (n + 3) & ~3
+        unit = 4 * self.world
+        buckets = [[] for _ in range(self.n_buckets)]
+        for p in ps:
+            if p.dtype != torch.float32 or not _dense_same_layout([p.data]):
+                raise _lib.VlsfrError("PartitionedSGD: parameters must be dense fp32 tensors")
+            buckets[self._bucket_of(p)].append(p)
+        ranges, off = [], 0
+        for bp in buckets:
+            n = sum(pad4(p.numel()) for p in bp)
+            n = (n + unit - 1) // unit * unit
+            ranges.append((off, n))
+            off += n
+        flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        for (start, _), bp in zip(ranges, buckets):
+            o = start
+            for p in bp:
+                vp = torch.as_strided(flat_p, p.shape, p.stride(), storage_offset=o)
+                vg = torch.as_strided(flat_g, p.shape, p.stride(), storage_offset=o)
+                vp.copy_(p.data)
+                if p.grad is not None:
+                    vg.copy_(p.grad)
+                p.data = vp
+                p.grad = vg
+                owner = getattr(p, "_vlsfr_owner", None)
+                if owner is not None:
+                    owner.weights_dirty = True
+                o += pad4(p.numel())
+        shard = lambda buf, start, n: buf[start + self.rank * (n // self.world):start + (self.rank + 1) * (n // self.world)]
+        self._part = dict(
+            buckets=buckets, ranges=ranges, flat_p=flat_p, flat_g=flat_g,
+            pshard=[shard(flat_p, s, n).clone() for s, n in ranges],       # fp32 master slices of this rank
+            gshard=[torch.zeros(n // self.world, dtype=torch.float32, device=dev) for _, n in ranges],
+            mshard=[torch.zeros(n // self.world, dtype=torch.float32, device=dev) for _, n in ranges])
+        self._flat_grad = flat_g
+        self._flat_key = tuple(p.grad.data_ptr() for p in ps)
+        return self._part
+
+    def flat_grad(self):
+        return self.partition()["flat_g"]
+
+    def zero_grad(self, set_to_none=False):
+        self.partition()["flat_g"].zero_()
+
+    # ------------------------------------------------------------------------------------------
+    def reduce_bucket(self, b):
+        """Sum of bucket b's gradients over the ranks, this rank's slice only (on the current stream)."""
+        part = self.partition()
+        start, n = part["ranges"][b]
+        self.comm.reduce_scatter_sum(part["gshard"][b], part["flat_g"][start:start + n])
+
+    def _update_shards(self, group):
+        part = self._part
+        groups = [(part["pshard"][b], part["gshard"][b], part["mshard"][b]) for b in range(self.n_buckets)
+                  if part["pshard"][b].numel()]
+        cache = self._caches.setdefault("shards", _TableCache())
+        tab = cache.get(groups, part["flat_p"].device)
+        fn = _lib.lib().vlsfr_sgd_nesterov
+        fn.restype = ctypes.c_int
+        _lib.check(fn(ctypes.c_void_p(tab.data_ptr()), ctypes.c_int32(tab.shape[0]), ctypes.c_float(group["lr"]),
+                      ctypes.c_float(group["momentum"]), ctypes.c_float(group["weight_decay"]),
+                      ctypes.c_int32(int(group["nesterov"])),
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "vlsfr_sgd_nesterov")
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """Expects reduce_bucket(b) to have run for every bucket since the last backward pass."""
+        part = self.partition()
+        if len(self.param_groups) != 1:
+            raise _lib.VlsfrError("PartitionedSGD: one parameter group")
+        self._update_shards(self.param_groups[0])
+        for b, (start, n) in enumerate(part["ranges"]):
+            if n:
+                self.comm.all_gather_into(part["flat_p"][start:start + n], part["pshard"][b])
+        for p in self._params():
+            owner = getattr(p, "_vlsfr_owner", None)
+            if owner is not None:
+                owner.weights_dirty = True
+        return None
+
+    # ------------------------------------------------------------------------------------------
+    def consolidate_state(self):
+        """All-gathers the momentum slices and exposes them as the per-parameter `momentum_buffer` entries torch's
+        Optimizer.state_dict() serialises (collective: every rank calls it; used for checkpoints)."""
+        part = self.partition()
+        for b, ((start, n), bp) in enumerate(zip(part["ranges"], part["buckets"])):
+            full = torch.empty(n, dtype=torch.float32, device=part["flat_p"].device)
+            self.comm.all_gather_into(full, part["mshard"][b])
+            o = 0
+            for p in bp:
+                self.state[p]["momentum_buffer"] = torch.as_strided(full, p.shape, p.stride(), storage_offset=o).clone()
+                o += (p.numel() + 3) & ~3
+
+    def scatter_state(self):
+        """Inverse of consolidate_state (after load_state_dict): this rank's momentum slices from the full buffers."""
+        part = self.partition()
+        for b, ((start, n), bp) in enumerate(zip(part["ranges"], part["buckets"])):
+            full = torch.zeros(n, dtype=torch.float32, device=part["flat_p"].device)
+            o = 0
+            for p in bp:
+                mb = self.state.get(p, {}).get("momentum_buffer")
+                if mb is not None:
+                    torch.as_strided(full, p.shape, p.stride(), storage_offset=o).copy_(mb)
+                o += (p.numel() + 3) & ~3
+            k = n // self.world
+            part["mshard"][b].copy_(full[self.rank * k:(self.rank + 1) * k])

@@ -4,56 +4,194 @@ The reference has no distributed code; the semantics defined here
 *result == single-process reference on the rank-order concatenation of all ranks' batches*
 (BatchNorm statistics stay per rank, like DistributedDataParallel without SyncBN):
 
-  * backbones: data parallel — every rank runs its own B rows; parameter gradients are summed
-    with one all-reduce over a flat gradient buffer (the loss normalisers are already global, so the
-    sum is the reference gradient);
+  * backbones: data parallel — every rank runs its own B rows.  Parameter gradients are summed bucket by bucket
+    with reduce-scatter on a communication stream WHILE the backward pass still runs (the backbone executor
+    records one event per bucket, csrc/iresnet.cpp vlsfr_iresnet_backward_staged); each rank then updates its
+    1/W slice of the parameters against its slice of the momentum (optim.fused.PartitionedSGD, ZeRO-1) and the
+    updated slices are all-gathered.  The loss normalisers are global, so the summed gradient is the reference's.
   * Dynamic Class Pool, two forms:
-      - `ShardedFFC` (default for N > 1): the pool is split by slot range over the ranks
-        (queue[2, Q/W, D] per GPU).  p, g are all-gathered over RCCL, the labels over a gloo side group
-        (no device sync); every rank replays the identical LRU bookkeeping, sweeps ITS slots for ALL
-        rows, and the softmax state is combined with all-reduce(max) + all-reduce(sum) of
-        (O, T, L, zt) (head.ShardedDcpHead) — three small collectives per pass.
-      - `DataParallelFFC`: replicated pool, every rank sweeps the whole pool for its own rows; no
-        softmax collective (the A/B baseline, and the fallback when the pool does not divide over the ranks).
-        SV under the sharded pool adds one small all-reduce(max) of the hard-example thresholds per pass.
+      - `ShardedFFC` (default for N > 1): the pool is split by slot range over the ranks (queue[2, Q/W, D] per
+        GPU, built shard-local by ffc.build_pool).  Per pass: ONE all-gather of the packed (p | g) rows; every rank
+        replays the identical LRU bookkeeping and sweeps ITS slots for ALL W*B rows (head.ShardedDcpHead); the
+        per-row softmax states are combined with an all-reduce(max) of the reference exponents [W*B, 2] and ONE
+        reduce-scatter(sum) of the packed (O, T, L, zt) rows, after which every rank holds the loss terms and dL/dp
+        of ITS OWN rows only; an all-gather of top-k candidates is added only when a batch has outlier rows, and SV
+        adds one small all-reduce(max) of the hard-example thresholds.
+      - `DataParallelFFC`: replicated pool, every rank sweeps the whole pool for its own rows; no softmax
+        collective (the A/B baseline, and the fallback when the pool does not divide over the ranks).
+  * labels are host arrays in the reference (main.py:53-60) and the LRU bookkeeping is host work, so they are
+    exchanged once per step over a gloo side group: a device collective would force the host to wait for the
+    stream before it can run the bookkeeping, i.e. serialise kernel issue with kernel execution.
+
+The N > 1 path has been exercised with 2 ranks over gloo (CPU tests; one-GPU rehearsal in tests/test_parallel_gpu.py);
+RCCL itself runs in the driver's multi-GPU bench only (no multi-GPU box is available to the build).
 """
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _lib
+
+
+class Comm(object):
+    """The collectives of the step on device tensors.  Backend "nccl" (= RCCL on ROCm) runs them in place; under
+    gloo (CPU tests, the 2-rank rehearsal on a 1-GPU box) the same calls stage through host memory."""
+
+    def __init__(self, dist, group=None):
+        self.dist, self.group = dist, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.rccl = dist.get_backend(group) == "nccl"
+
+    def _host(self, t):
+        return t if not t.is_cuda or self.rccl else t.cpu()
+
+    def broadcast(self, t, src=0):
+        c = self._host(t)
+        self.dist.broadcast(c, src=src, group=self.group)
+        if c is not t:
+            t.copy_(c)
+        return t
+
+    def all_reduce(self, t, op="sum"):
+        rop = self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM
+        c = self._host(t)
+        self.dist.all_reduce(c, op=rop, group=self.group)
+        if c is not t:
+            t.copy_(c)
+        return t
+
+    def all_gather(self, t):
+        """-> [world, *t.shape]"""
+        t = t.contiguous()
+        if self.rccl or not t.is_cuda:
+            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+            if self.rccl:
+                self.dist.all_gather_into_tensor(out, t, group=self.group)
+            else:
+                self.dist.all_gather(list(out.unbind(0)), t, group=self.group)
+            return out
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
+        self.dist.all_gather(parts, t.cpu(), group=self.group)
+        return torch.stack(parts).to(t.device)
+
+    def all_gather_into(self, out, shard):
+        """out (flat, world * shard.numel()) <- concatenation of every rank's shard."""
+        if self.rccl:
+            self.dist.all_gather_into_tensor(out, shard, group=self.group)
+            return out
+        out.copy_(self.all_gather(shard).reshape(-1))
+        return out
+
+    def reduce_scatter_sum(self, out, inp):
+        """out <- this rank's 1/world slice (along dim 0) of the sum of `inp` over the ranks."""
+        if self.rccl:
+            self.dist.reduce_scatter_tensor(out, inp, group=self.group)
+            return out
+        c = inp.cpu() if inp.is_cuda else inp.clone()          # gloo has no reduce-scatter: all-reduce and slice
+        self.dist.all_reduce(c, group=self.group)
+        n = c.shape[0] // self.world
+        out.copy_(c[self.rank * n:(self.rank + 1) * n])
+        return out
+
+    # the names head.ShardedDcpHead uses
+    def all_reduce_max(self, t):
+        return self.all_reduce(t, "max")
+
+    def all_reduce_sum(self, t):
+        return self.all_reduce(t, "sum")
+
+    def reduce_scatter_rows(self, t):
+        out = torch.empty((t.shape[0] // self.world,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        return self.reduce_scatter_sum(out, t.contiguous())
+
 
 class DataParallelFFC(object):
+    """Data-parallel backbones over a replicated pool; also the base of ShardedFFC (everything but the head)."""
+
     def __init__(self, model, dist):
         self.m = model
         self.dist = dist
-        self.world = dist.get_world_size()
-        self.rank = dist.get_rank()
-        self.cpu_group = dist.new_group(backend="gloo")
-        self.rccl = dist.get_backend() == "nccl"   # "nccl" IS RCCL on ROCm; gloo only in the 1-GPU rehearsal
-        self._flat = None
-        # identical starting point on every rank
-        pre_sharded = getattr(model, 'pool_shard', None) is not None   # every rank built its own slots (ffc.build_pool)
+        self.comm = Comm(dist)
+        self.world, self.rank = self.comm.world, self.comm.rank
+        self.rccl = self.comm.rccl
+        self.cpu_group = dist.new_group(backend="gloo")        # labels (host arrays) travel here, see module docstring
+        self._labels = None
+        self._comm_stream = None
+        # identical starting point on every rank (a pool built shard-local is already consistent by construction)
+        pre_sharded = getattr(model, 'pool_shard', None) is not None
         for t in list(model.parameters()) + [b for n, b in model.named_buffers() if not (pre_sharded and n == 'queue')]:
-            if self.rccl:
-                dist.broadcast(t.data, src=0)
-            else:
-                c = t.data.cpu()
-                dist.broadcast(c, src=0)
-                t.data.copy_(c)
+            self.comm.broadcast(t.data)
+        for net in (getattr(model, "probe_net", None),):
+            if net is not None:
+                net.__dict__["signal_stages"] = True           # the backward passes record their bucket events
 
-    def _gather_labels(self, lab):
+    # ---- the optimizer of the step ----------------------------------------------------------------
+    def make_optimizer(self, lr, momentum=0.9, weight_decay=1e-4, nesterov=True):
+        """The partitioned SGD over the probe net's trainable parameters, bucketed as the backbone's backward pass
+        completes them."""
+        from .optim.fused import PartitionedSGD
+        net = self.m.probe_net
+        names = {id(p): n for n, p in net.named_parameters()}
+        params = [p for p in self.m.parameters() if p.requires_grad]
+        return PartitionedSGD(params, lr, momentum=momentum, weight_decay=weight_decay, nesterov=nesterov, comm=self.comm,
+                              bucket_of=lambda p: net.bucket_of(names[id(p)]), n_buckets=net.N_BUCKETS)
+
+    def _stream(self, device):
+        if self._comm_stream is None or self._comm_stream.device != device:
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return self._comm_stream
+
+    def reduce_gradients(self, optimizer=None):
+        """Call right after loss.backward() (which only ENQUEUES the backward passes): per bucket, the communication
+        stream waits for the events both backward passes record when the bucket's gradients are complete, then
+        reduce-scatters it — the reduction of layer4 overlaps the backward pass of layer3, and so on.  The main
+        stream waits for the communication stream before optimizer.step()."""
+        from .optim.fused import PartitionedSGD
+        if not isinstance(optimizer, PartitionedSGD):
+            return self._all_reduce_gradients(optimizer)
+        net = self.m.probe_net
+        main = torch.cuda.current_stream()
+        comm_s = self._stream(main.device)
+        L = _lib.lib()
+        evs = [net.stage_events(slot) for slot in (0, 1)]
+        for b in range(optimizer.n_buckets):
+            for slot in (0, 1):
+                _lib.check(L.vlsfr_stream_wait_event(ctypes.c_void_p(comm_s.cuda_stream), ctypes.c_void_p(evs[slot][b])),
+                           "vlsfr_stream_wait_event")
+            with torch.cuda.stream(comm_s):
+                optimizer.reduce_bucket(b)
+        main.wait_stream(comm_s)
+
+    def _all_reduce_gradients(self, optimizer=None):
+        """Replicated update (FusedSGD / any torch optimizer): one all-reduce over the flat gradient buffer."""
+        flat = optimizer.flat_grad() if optimizer is not None and hasattr(optimizer, "flat_grad") else None
+        if flat is not None:
+            self.comm.all_reduce(flat)
+            return
+        grads = [p.grad for p in self.m.probe_net.parameters() if p.requires_grad and p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        self.comm.all_reduce(flat)
+        for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(s)
+
+    # ---- one step -----------------------------------------------------------------------------------
+    def exchange_labels(self, x_label, y_label):
+        """Both label vectors of every rank in one gloo all-gather -> (x_labels, y_labels) of the whole batch."""
+        lab = torch.stack([torch.as_tensor(x_label, dtype=torch.int64).cpu(), torch.as_tensor(y_label, dtype=torch.int64).cpu()])
+        out = [torch.empty_like(lab) for _ in range(self.world)]
+        self.dist.all_gather(out, lab.contiguous(), group=self.cpu_group)
+        allv = torch.stack(out)                                   # [W, 2, B]
+        return allv[:, 0].reshape(-1).numpy(), allv[:, 1].reshape(-1).numpy()
+
+    def _gather_labels(self, lab):                                # one vector (tests, tools)
         lab = torch.as_tensor(lab, dtype=torch.int64).cpu().contiguous()
         out = [torch.empty_like(lab) for _ in range(self.world)]
         self.dist.all_gather(out, lab, group=self.cpu_group)
         return torch.cat(out).numpy()
 
-    def _gather_rows(self, g):
-        if self.rccl:
-            out = torch.empty(self.world * g.shape[0], g.shape[1], dtype=g.dtype, device=g.device)
-            self.dist.all_gather_into_tensor(out, g.contiguous())
-            return out
-        parts = [torch.empty(g.shape, dtype=g.dtype) for _ in range(self.world)]   # rehearsal path (gloo, host)
-        self.dist.all_gather(parts, g.cpu().contiguous())
-        return torch.cat(parts).to(g.device)
+    def _gather_rows(self, t):
+        return self.comm.all_gather(t).reshape((-1,) + tuple(t.shape[1:]))
 
     def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
         m = self.m
@@ -61,72 +199,22 @@ class DataParallelFFC(object):
         p, g = m.embed_pair(p_data, g_data, update_gallery=transactional)
         with torch.no_grad():
             g_all = self._gather_rows(g)
-        pl = self._gather_labels(probe_label)
-        gl = self._gather_labels(gallery_label)
-        return head.run_pass(p, g_all, pl, gl, transactional, row_offset=self.rank * p.shape[0])
+        return head.run_pass(p, g_all, probe_label, gallery_label, transactional, row_offset=self.rank * p.shape[0])
 
     def __call__(self, x, y, x_label, y_label):
-        loss2 = self._pass(x, y, x_label, y_label, True)      # ffc.py:265
-        loss1 = self._pass(y, x, y_label, x_label, False)     # ffc.py:266
+        xl, yl = self.exchange_labels(x_label, y_label)
+        loss2 = self._pass(x, y, xl, yl, True)        # ffc.py:265
+        loss1 = self._pass(y, x, yl, xl, False)       # ffc.py:266
         return loss1 + loss2
 
-    def reduce_gradients(self, optimizer=None):
-        """Sum the probe-net gradients over ranks (one all-reduce on a flat buffer)."""
-        flat = optimizer.flat_grad() if optimizer is not None and hasattr(optimizer, "flat_grad") else None
-        if flat is not None:
-            if self.rccl:
-                self.dist.all_reduce(flat)
-            else:
-                c = flat.cpu()
-                self.dist.all_reduce(c)
-                flat.copy_(c)
-            return
-        grads = [p.grad for p in self.m.probe_net.parameters() if p.requires_grad and p.grad is not None]
-        flat = torch._utils._flatten_dense_tensors(grads)
-        self.dist.all_reduce(flat)
-        for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-            g.copy_(s)
-
     def global_loss(self, loss):
-        t = loss.detach().clone()
-        self.dist.all_reduce(t)
-        return t
-
-
-class _DistComm(object):
-    """The three collectives of head.ShardedDcpHead over torch.distributed (RCCL; gloo rehearsal via host)."""
-
-    def __init__(self, dist, rccl):
-        self.dist, self.rccl, self.world = dist, rccl, dist.get_world_size()
-
-    def _reduce(self, t, op):
-        if self.rccl:
-            self.dist.all_reduce(t, op=op)
-            return t
-        c = t.cpu()
-        self.dist.all_reduce(c, op=op)
-        return c.to(t.device)
-
-    def all_reduce_max(self, t):
-        return self._reduce(t, self.dist.ReduceOp.MAX)
-
-    def all_reduce_sum(self, t):
-        return self._reduce(t, self.dist.ReduceOp.SUM)
-
-    def all_gather(self, t):
-        t = t.contiguous()
-        if self.rccl:
-            out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-            self.dist.all_gather_into_tensor(out, t)
-            return out
-        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(self.world)]
-        self.dist.all_gather(parts, t.cpu())
-        return torch.stack(parts).to(t.device)
+        """Every rank returns its share of the loss (the shares sum to the reference loss); this is the sum."""
+        return self.comm.all_reduce(loss.detach().clone())
 
 
 class ShardedFFC(DataParallelFFC):
-    """Identity-sharded pool: after construction `model.queue` holds only this rank's slots
-    [rank * Q / W, (rank + 1) * Q / W) (use `gather_pool()` for a checkpoint)."""
+    """Identity-sharded pool: `model.queue` holds only this rank's slots [rank * Q / W, (rank + 1) * Q / W)
+    (`pool_state()` / `load_pool_state()` for shard-wise checkpoints, `gather_pool()` for a reference-format one)."""
 
     def __init__(self, model, dist):
         super(ShardedFFC, self).__init__(model, dist)
@@ -147,23 +235,37 @@ class ShardedFFC(DataParallelFFC):
         model._head = None
         self.head = ShardedDcpHead(shard, self.rank, self.world, Q, model.scale, model.margin, model.loss_type,
                                    precise=model.precise_head, lru=state.lru, qp=state.qp)
-        self.comm = _DistComm(dist, self.rccl)
 
     def gather_pool(self):
+        """The whole pool [2, Q, D] on every rank (a collective; reference checkpoint format, main.py:85)."""
         return self.comm.all_gather(self.head.queue).permute(1, 0, 2, 3).reshape(2, -1, self.head.D)
+
+    def pool_state(self):
+        """This rank's part of a shard-wise checkpoint: its pool slots and the (replicated) allocator state."""
+        keys, slots = self.head.lru.state_arrays()
+        return dict(rank=self.rank, world=self.world, slot_lo=self.head.slot_lo, fc_shard=self.head.queue.cpu(),
+                    lru_keys=torch.from_numpy(keys.copy()), lru_slots=torch.from_numpy(slots.copy()),
+                    qp=torch.from_numpy(self.head.qp.copy()))
+
+    def load_pool_state(self, st):
+        if (int(st["rank"]), int(st["world"])) != (self.rank, self.world):
+            raise ValueError("pool shard of rank %d/%d loaded on rank %d/%d" % (st["rank"], st["world"], self.rank, self.world))
+        with torch.no_grad():
+            self.head.queue.copy_(st["fc_shard"].to(self.head.queue.device))
+        self.head.lru.reset()
+        self.head.lru.restore_arrays(st["lru_keys"].numpy(), st["lru_slots"].numpy())
+        self.head.qp[:] = st["qp"].numpy()
 
     def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
         from .head import _HeadFn
         m = self.m
         p, g = m.embed_pair(p_data, g_data, update_gallery=transactional)
+        B, D = p.shape
         with torch.no_grad():
-            g_all = self._gather_rows(g)
-            p_all = self._gather_rows(p.detach())
-        pl = self._gather_labels(probe_label)
-        gl = self._gather_labels(gallery_label)
-        st = self.head.partial(p_all, g_all, pl, gl, transactional, comm=self.comm)
-        st = self.head.combine(st, self.comm)
+            pg = self._gather_rows(torch.cat([p.detach(), g], dim=1))        # ONE all-gather: [W * B, 2 D]
+            p_all, g_all = pg[:, :D].contiguous(), pg[:, D:].contiguous()
+        st = self.head.partial(p_all, g_all, probe_label, gallery_label, transactional, comm=self.comm)
+        st = self.head.combine(st, self.comm, own_rows=(self.rank * B, (self.rank + 1) * B))
         loss, dP = self.head.finish(st)
-        B = p.shape[0]
-        # every rank holds the same global loss; its autograd edge carries this rank's rows of dL/dp
-        return _HeadFn.apply(p, loss.reshape(()), dP[self.rank * B:(self.rank + 1) * B].contiguous())
+        # this rank's share of the loss (its own rows); the autograd edge carries its rows of dL/dp
+        return _HeadFn.apply(p, loss.reshape(()), dP.contiguous())
