@@ -379,9 +379,9 @@ def test_reference_loop_shape_with_autocast_and_gradscaler():
         assert loss.dtype == torch.float32
         outs.append((float(loss.detach()), np.concatenate([p.detach().float().cpu().numpy().ravel() for p in m.probe_net.parameters()]),
                      m.queue.clone(), m.lru.state_dict(), m._state().qp.copy()))
-    (l0, w0, q0, s0, qp0), (l1, w1, _, _, _), (l2, w2, q2, s2, qp2) = outs
-    noise_l, noise_w = abs(l0 - l1) / abs(l0), rel_l2(w1, w0)
+    (l0, w0, q0, s0, qp0), (l1, w1, q1, _, _), (l2, w2, q2, s2, qp2) = outs
+    noise_l, noise_w, noise_q = abs(l0 - l1) / abs(l0), rel_l2(w1, w0), float((q0 - q1).abs().max())
     assert abs(l0 - l2) / abs(l0) <= max(4 * noise_l, 1e-3)
     assert rel_l2(w2, w0) <= max(4 * noise_w, 1e-4)
     assert s0 == s2 and (qp0 == qp2).all()
-    assert float((q0 - q2).abs().max()) <= 5e-3
+    assert float((q0 - q2).abs().max()) <= max(4 * noise_q, 1e-2)      # pool rows are unit vectors written by the gallery net
