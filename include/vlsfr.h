@@ -295,6 +295,12 @@ int vlsfr_cast_weights(const vlsfr_cast_entry* entries, int32_t n, void* stream)
 int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, int32_t stride,
                       void* stream);
 int vlsfr_unpad_add(const float* src, float* dst, int32_t rows, int32_t Ksrc, int32_t Kdst, void* stream);
+/* The loader's image transform on the device.  Replaces util/lmdb_loader.py:109-127 (MultiLMDBDataset.__getitem__
+ * after cv2.imdecode) and :206-233 (PairLMDBDataset): raw = decoded uint8 pixels [N][H][W][C], C = 3 (BGR, the
+ * cv2 order) or 1 (grey: replicated to three planes, :112-117); flip = uint8 [N] (non-zero: cv2.flip(img, 1), drawn
+ * by the host with p = 0.5, :109) or NULL; out = fp32 [N][3][H][W] = (v - 127.5) * 0.0078125 (exact in fp32). */
+int vlsfr_faces_normalize(const uint8_t* raw, const uint8_t* flip, float* out, int32_t N, int32_t H, int32_t W,
+                          int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7. iResNet backbone executor (host object, device work).  One call = one whole forward or

@@ -385,3 +385,15 @@ def test_reference_loop_shape_with_autocast_and_gradscaler():
     assert rel_l2(w2, w0) <= max(4 * noise_w, 1e-4)
     assert s0 == s2 and (qp0 == qp2).all()
     assert float((q0 - q2).abs().max()) <= max(4 * noise_q, 1e-2)      # pool rows are unit vectors written by the gallery net
+
+
+def test_main_trains_from_a_face_store(tmp_path):
+    """main.py's loop fed by the reference's two datasets over a FaceStore (data.py), images normalised on the GPU."""
+    from vlsfr_amd.data import make_synthetic_store
+    from vlsfr_amd.main import parse_args, train
+    store, kv = make_synthetic_store(str(tmp_path / "db"), "faces", 40, 3, hw=112, seed=4)
+    conf = parse_args(["--net_type", "irtiny", "--feat_dim", "32", "--queue_size", "64", "--batch_size", "8", "--print_freq", "2",
+                       "--iters_per_epoch", "3", "--saved_dir", "", "--data_store", store, "--data_kv", kv])
+    net, loss = train(conf, log=lambda *_: None)
+    assert np.isfinite(float(loss.detach()))
+    assert len(net.lru.state_dict()) > 0 and max(k for k, _ in net.lru.state_dict()) < 40      # labels come from the kv file

@@ -679,6 +679,37 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* x, u16* o
   }
 }
 
+// Loader transform on the device (reference util/lmdb_loader.py:109-127, :206-233): decoded uint8 pixels
+// [N][H][W][C] (C = 3: BGR as cv2.imdecode delivers them, C = 1: grey, replicated to three planes) ->
+// fp32 [N][3][H][W] = (v - 127.5) * 0.0078125, mirrored left-right where flip[n] != 0 (cv2.flip(img, 1)).
+// One thread per 4 output pixels of one plane row: 16-byte stores, the uint8 reads of a row stay in L1/L2.
+__global__ __launch_bounds__(256) void faces_normalize_kernel(const uint8_t* raw, const uint8_t* flip, float* out, int N, int H,
+                                                              int W, int C) {
+  const int W4 = (W + 3) / 4;
+  const int64_t total = (int64_t)N * 3 * H * W4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int w4 = (int)(i % W4);
+    int64_t r = i / W4;
+    const int h = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % 3);
+    const int n = (int)(r / 3);
+    const bool fl = flip && flip[n];
+    const uint8_t* src = raw + ((size_t)n * H + h) * W * C + (C == 3 ? c : 0);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w = w4 * 4 + j;
+      const int ws = fl ? W - 1 - w : w;
+      v[j] = w < W ? ((float)src[(size_t)ws * C] - 127.5f) * 0.0078125f : 0.f;
+    }
+    float* dst = out + (((size_t)n * 3 + c) * H + h) * W + w4 * 4;
+    if (w4 * 4 + 3 < W && ((W & 3) == 0)) *(f32x4*)dst = (f32x4){v[0], v[1], v[2], v[3]};
+    else
+      for (int j = 0; j < 4 && w4 * 4 + j < W; ++j) dst[j] = v[j];
+  }
+}
+
 // dst[rows][Kdst] += src[rows][Ksrc][:Kdst]   (un-pad the stem weight gradient)
 __global__ void unpad_add_kernel(const float* src, float* dst, int rows, int Ksrc, int Kdst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -892,6 +923,16 @@ int vlsfr_stem_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int3
   hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks_for((int64_t)N * Ho * Wo, 256, 4096)), dim3(256), 0,
                      (hipStream_t)stream, x_nchw, (u16*)out, N, H, W, stride);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_stem_im2col");
+  return VLSFR_OK;
+}
+
+int vlsfr_faces_normalize(const uint8_t* raw, const uint8_t* flip, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                          void* stream) {
+  if (!raw || !out || N <= 0 || H <= 0 || W <= 0 || (C != 1 && C != 3))
+    return fail(VLSFR_EINVAL, "vlsfr_faces_normalize: bad argument (C must be 1 or 3)");
+  hipLaunchKernelGGL(faces_normalize_kernel, dim3(blocks_for((int64_t)N * 3 * H * ((W + 3) / 4), 256, 4096)), dim3(256), 0,
+                     (hipStream_t)stream, raw, flip, out, N, H, W, C);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_faces_normalize");
   return VLSFR_OK;
 }
 

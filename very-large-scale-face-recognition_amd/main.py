@@ -189,7 +189,14 @@ def train(conf, log=print):
             continue
         if optim_config['scheduler'] != 'ReduceLROnPlateau':
             lr_scheduler.update(epoch, 0.0)
-        data = SyntheticFaces(conf.num_class, conf.batch_size, conf.iters_per_epoch, dev, seed=1000 * epoch + rank)
+        if getattr(conf, "data_store", ""):
+            # the reference's two datasets (main.py:102-111) over a FaceStore; transform on the GPU (data.py)
+            from .data import DeviceBatcher, MultiLMDBDataset, PairLMDBDataset
+            stores, kvs = conf.data_store.split(","), conf.data_kv.split(",")
+            data = DeviceBatcher(MultiLMDBDataset(stores, kvs), PairLMDBDataset(stores, kvs), conf.batch_size, dev,
+                                 n_batches=conf.iters_per_epoch, seed=1000 * epoch + rank)
+        else:
+            data = SyntheticFaces(conf.num_class, conf.batch_size, conf.iters_per_epoch, dev, seed=1000 * epoch + rank)
         real_iter, loss = train_one_epoch(data, ffc_net, step_model, optim, epoch + 1, conf, real_iter,
                                           optim_config['scheduler'], lr_scheduler, optim_config['epochs'], world, log,
                                           skip=max(0, start_iter - epoch * conf.iters_per_epoch))
@@ -214,6 +221,9 @@ def parse_args(argv=None):
     conf.add_argument('--num_class', type=int, default=100000, help='identities of the synthetic dataset')
     conf.add_argument('--iters_per_epoch', type=int, default=100)
     conf.add_argument('--optim_config', type=str, default='', help='typed-JSON file in the format of config/optim_config')
+    conf.add_argument('--data_store', type=str, default='', help='comma-separated FaceStore directories (data.py; the reference '
+                      'hard-codes its LMDB paths at main.py:168-169); empty = synthetic batches')
+    conf.add_argument('--data_kv', type=str, default='', help='the kv files of --data_store ("<key> <label>" lines)')
     conf.add_argument('--resume', type=str, default='', help='checkpoint written by this driver (or by the reference) to continue from')
     return conf.parse_args(argv)
 
