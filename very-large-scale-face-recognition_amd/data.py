@@ -248,18 +248,19 @@ class DeviceBatcher(object):
         self.inst, self.ids, self.B, self.dev = inst_dataset, id_dataset, batch_size, device
         self.n = n_batches if n_batches is not None else len(inst_dataset) // batch_size
         self.rng = np.random.default_rng(seed)
-        self._id_order = iter(())
+        self._id_order = []
 
     def __len__(self):
         return self.n
 
     def _next_ids(self, k):
-        out = []
-        while len(out) < k:
-            try:
-                out.append(next(self._id_order))
-            except StopIteration:                                                # main.py:42-46: re-arm the id iterator
-                self._id_order = iter(self.rng.permutation(len(self.ids)).tolist())
+        """k distinct identities: the next k of a random permutation; when fewer than k are left the id iterator is
+        re-armed (main.py:42-46) — a partial last batch is dropped rather than mixed with the next epoch's ids."""
+        if k > len(self.ids):
+            raise ValueError("the id dataset holds %d identities, a batch needs %d" % (len(self.ids), k))
+        if len(self._id_order) < k:
+            self._id_order = self.rng.permutation(len(self.ids)).tolist()
+        out, self._id_order = self._id_order[:k], self._id_order[k:]
         return out
 
     def __iter__(self):
