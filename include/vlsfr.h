@@ -256,8 +256,10 @@ int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* strea
 /* y = prelu(bn(x)) + residual from the statistics `sums` of x (every block folds the replicas into
  * scale / shift itself; mean, invstd are saved for the backward pass; running_* get the momentum
  * update with the unbiased variance).  slope / residual / running_* may be NULL.  out_sums
- * (optional): the statistics [REPL][2][C] of y, for the next BatchNorm.  out_nchw writes y in the
- * [n][c][hw] flatten order of the reference's fc input (HW = rows per image). */
+ * (optional): the statistics [REPL][2][C] of y, for the next BatchNorm.  out_nchw bit 0 writes y in the
+ * [n][c][hw] flatten order of the reference's fc input (HW = rows per image); bit 1 applies ReLU AFTER the
+ * residual add, y = relu(bn(x) + residual) — the block ending of model/resnet_std.py:97-105 (needs residual,
+ * no slope, no out_sums). */
 int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums,
                    const float* gamma, const float* beta, const float* slope, const void* residual,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
@@ -360,6 +362,40 @@ int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const
                             void* stream);
 int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const float* const* params,
                              float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 7c. torchvision-style ResNet executor (Bottleneck): same contract as section 7 for reference
+ *     model/resnet_std.py:55-104 (Bottleneck.forward) and :106-206 (ResNet: 7x7/2 stem, BN, ReLU, 3x3/2 max-pool,
+ *     four stages, flatten -> fc -> BatchNorm1d -> normalise), training mode; `--net_type r50` = layers {3,4,6,3}
+ *     (resnet_std.py:242-251), 224 x 224 input (fc is 2048*7*7 wide, :140).  Parameter order = registration order
+ *     (conv1.weight, bn1.*, layer1.0.conv1.weight, layer1.0.bn1.*, conv2, bn2, conv3, bn3, downsample.0.weight,
+ *     downsample.1.*, ..., fc.weight, fc.bias, features.weight, features.bias); features.weight is trainable here.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vlsfr_resnet vlsfr_resnet;
+int vlsfr_resnet_create(const int32_t* layers /*[4]*/, int32_t feat_dim, int32_t batch, int32_t image_hw,
+                        vlsfr_resnet** out);
+void vlsfr_resnet_destroy(vlsfr_resnet* n);
+int32_t vlsfr_resnet_num_params(const vlsfr_resnet* n);
+int32_t vlsfr_resnet_num_bn(const vlsfr_resnet* n);
+size_t vlsfr_resnet_wcache_bytes(const vlsfr_resnet* n);
+size_t vlsfr_resnet_ctx_bytes(const vlsfr_resnet* n);
+size_t vlsfr_resnet_scratch_bytes(const vlsfr_resnet* n);
+int vlsfr_resnet_prepare_weights(const vlsfr_resnet* n, const float* const* params, void* wcache, void* stream);
+int vlsfr_resnet_forward(const vlsfr_resnet* n, const float* x_nchw, const float* const* params,
+                         float* const* running, const void* wcache, void* ctx, void* scratch, float* emb_out,
+                         void* stream);
+int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float* const* params,
+                          float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
+/* Its operator kernels beyond sections 5 / 6 (NHWC bf16): the 7x7 / stride 2 / pad 3 stem as im2col rows
+ * [N*Ho*Wo][160] (k = (r*7+s)*3+c, 147 taps zero padded; resnet_std.py:127-128), nn.MaxPool2d(3, 2, 1) forward and
+ * backward (:131; the gradient goes to the first maximum of a window, as torch's does) and the backward of the
+ * ReLU that follows the residual add (:103; in_nchw: dy and y in the [n][c][hw] flatten order, dx NHWC). */
+int vlsfr_stem7_im2col(const float* x_nchw, void* out, int32_t N, int32_t H, int32_t W, void* stream);
+int vlsfr_maxpool3x3s2_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int vlsfr_maxpool3x3s2_bwd(const void* dy, const void* x, const void* y, void* dx, int32_t N, int32_t H, int32_t W,
+                           int32_t C, void* stream);
+int vlsfr_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t M, int32_t C, int32_t HW, int32_t in_nchw,
+                        void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 8. Parameter sweeps (device), one launch over all tensors.

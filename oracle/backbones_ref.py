@@ -4,6 +4,7 @@ CPU restatement (plain PyTorch CPU ops, fp32 or fp64) of the two backbones on th
 driven by a flat state dict that uses the reference's parameter names:
   * iResNet      — reference model/resnet_arcface.py:26-55 (IBasicBlock), :58-152 (IResNet)
   * MobileFaceNet — reference model/mobilefacenet_def.py:18-25, :27-52, :55-74, :77-123
+  * ResNet (torchvision style, Bottleneck) — reference model/resnet_std.py:55-104, :106-206
 Both run in training mode (batch statistics, running-stat update with momentum 0.1, eps 1e-5),
 because the reference never calls .eval() on either net (ffc.py:22-23, main.py:116-121).
 
@@ -110,12 +111,49 @@ def mobilefacenet_state(feat_dim=128, gen=None):
     return sd
 
 
+RESNET_LAYERS = {"r50": (3, 4, 6, 3), "r101": (3, 4, 23, 3), "rtiny": (1, 1, 1, 1)}
+
+
+def resnet_std_state(layers, feat_dim=512, gen=None, image_size=224):
+    """resnet_std.py:127-151: kaiming_normal(fan_out, relu) convolutions, BN 1/0, Linear default init."""
+    sd = {}
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = torch.randn(co, ci, k, k, generator=gen) * math.sqrt(2.0 / (co * k * k))
+
+    conv("conv1", 64, 3, 7)
+    _bn(sd, "bn1", 64)
+    cin = 64
+    for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), layers), start=1):
+        for bi in range(nblk):
+            pre = "layer%d.%d" % (li, bi)
+            conv(pre + ".conv1", planes, cin, 1)
+            _bn(sd, pre + ".bn1", planes)
+            conv(pre + ".conv2", planes, planes, 3)
+            _bn(sd, pre + ".bn2", planes)
+            conv(pre + ".conv3", planes * 4, planes, 1)
+            _bn(sd, pre + ".bn3", planes * 4)
+            if bi == 0:
+                conv(pre + ".downsample.0", planes * 4, cin, 1)
+                _bn(sd, pre + ".downsample.1", planes * 4)
+            cin = planes * 4
+    side = image_size // 32
+    fan_in = cin * side * side
+    sd["fc.weight"] = _uniform((feat_dim, fan_in), 1.0 / math.sqrt(fan_in), gen)
+    sd["fc.bias"] = _uniform((feat_dim,), 1.0 / math.sqrt(fan_in), gen)
+    _bn(sd, "features", feat_dim)
+    return sd
+
+
 def is_buffer(name):
     return name.endswith("running_mean") or name.endswith("running_var") or name.endswith("num_batches_tracked")
 
 
-def trainable(name):
-    """resnet_arcface.py:97-98 freezes features.weight; buffers never train."""
+def trainable(name, net_type=None):
+    """resnet_arcface.py:97-98 freezes features.weight of the iResNet (resnet_std.py does not: pass its net_type);
+    buffers never train."""
+    if net_type in RESNET_LAYERS:
+        return not is_buffer(name)
     return not is_buffer(name) and name != "features.weight"
 
 
@@ -205,6 +243,35 @@ def iresnet_forward(sd, x, layers, emulate_bf16=False):
     return F.normalize(h)
 
 
+def resnet_std_forward(sd, x, layers, emulate_bf16=False):
+    """resnet_std.py:184-203 (_forward_impl) with Bottleneck.forward (:82-104)."""
+    E = Emu(emulate_bf16)
+    conv = lambda h, name, stride, pad: E.R(F.conv2d(E.G(h), E.W(sd[name + ".weight"]), None, stride, pad))
+    h = conv(E.X(x), "conv1", 2, 3)
+    h = E.R(F.relu(_bn_train(sd, "bn1", h)))
+    h = E.R(F.max_pool2d(h, 3, 2, 1))
+    for li, nblk in enumerate(layers, start=1):
+        for bi in range(nblk):
+            pre = "layer%d.%d" % (li, bi)
+            stride = 2 if (bi == 0 and li > 1) else 1
+            o = conv(h, pre + ".conv1", 1, 0)
+            o = E.R(F.relu(_bn_train(sd, pre + ".bn1", o)))
+            o = conv(o, pre + ".conv2", stride, 1)
+            o = E.R(F.relu(_bn_train(sd, pre + ".bn2", o)))
+            o = conv(o, pre + ".conv3", 1, 0)
+            o = _bn_train(sd, pre + ".bn3", o)
+            if bi == 0:
+                idn = conv(h, pre + ".downsample.0", stride, 0)
+                idn = E.R(_bn_train(sd, pre + ".downsample.1", idn))
+            else:
+                idn = h
+            h = E.R(F.relu(o + idn))
+    h = torch.flatten(h, 1)
+    h = E.G(F.linear(h, E.W(sd["fc.weight"]), sd["fc.bias"]))
+    h = _bn_train(sd, "features", h)
+    return F.normalize(h)
+
+
 def mobilefacenet_forward(sd, x, emulate_bf16=False):
     E = Emu(emulate_bf16)
 
@@ -244,5 +311,9 @@ def make_backbone(net_type, feat_dim, gen=None, layers=None, emulate_bf16=False)
     """Returns (state_dict, forward(sd, x))."""
     if net_type == "mobile":
         return mobilefacenet_state(feat_dim, gen), (lambda sd, x: mobilefacenet_forward(sd, x, emulate_bf16))
+    if net_type in RESNET_LAYERS:
+        lay = tuple(layers) if layers is not None else RESNET_LAYERS[net_type]
+        size = 64 if net_type == "rtiny" else 224
+        return resnet_std_state(lay, feat_dim, gen, size), (lambda sd, x: resnet_std_forward(sd, x, lay, emulate_bf16))
     lay = tuple(layers) if layers is not None else IRESNET_LAYERS[net_type]
     return iresnet_state(lay, feat_dim, gen), (lambda sd, x: iresnet_forward(sd, x, lay, emulate_bf16))

@@ -111,9 +111,10 @@ class FFCRef(object):
                  gen=None, layers=None, dtype=torch.float32, emulate_bf16=False):
         assert loss_type in ("AM", "Arc", "SV")
         self.probe, self.fwd = bb.make_backbone(net_type, feat_dim, gen, layers, emulate_bf16)
+        self.net_type = net_type
         self.probe = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in self.probe.items()}
         for k, v in self.probe.items():
-            if bb.trainable(k):
+            if bb.trainable(k, net_type):
                 v.requires_grad_(True)
         # ffc.py:53-55: parameters are copied p -> g and frozen; gallery buffers keep their own defaults
         self.gallery = {k: v.detach().clone() for k, v in self.probe.items()}
@@ -125,7 +126,7 @@ class FFCRef(object):
         self.hard_neg = hard_neg_count(queue_size)
 
     def parameters(self):
-        return [v for k, v in self.probe.items() if bb.trainable(k)]
+        return [v for k, v in self.probe.items() if bb.trainable(k, self.net_type)]
 
     def ema(self):                                                               # ffc.py:139-145 (parameters only,
         with torch.no_grad():                                                    # frozen features.weight included)

@@ -285,11 +285,51 @@ def scheduler_vectors():
     print("scheduler_lrs.json: %d configs, %d points" % (len(out), sum(len(o["rows"]) for o in out)))
 
 
+def _sample(a):          # large tensors are kept as a strided sample of the flattened array (as in step_vectors)
+    flat = np.asarray(a).reshape(-1)
+    return flat[::max(1, flat.size // 4096)]
+
+
+def resnet_std_vectors():
+    """Forward + backward of the reference's torchvision-style ResNet (model/resnet_std.py) in float64 on CPU: one
+    Bottleneck per stage (the class the reference builds r50 from, :242-251), feat_dim 32, eight 224 x 224 images, seeded
+    weights (common.fill_state over the reference's own state dict names) -> embeddings, the gradient norm of every
+    parameter and samples of the gradient tensors for the loss sum(emb * c), c a seeded constant."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_resnet_std", "/root/reference/model/resnet_std.py")
+    ref_std = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_std)
+    net = ref_std.ResNet(ref_std.Bottleneck, [1, 1, 1, 1], feat_dim=32).double()
+    sd = common.fill_state({k: (v.detach().float() if v.is_floating_point() else v.detach().clone())
+                            for k, v in net.state_dict().items()}, 41)
+    net.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    net.train()
+    rng = np.random.default_rng(41)
+    x = common.images_from_u8(common.synth_images_u8(rng, 8, hw=224)).double()
+    c = torch.from_numpy(rng.standard_normal((8, 32)))
+    emb = net(x)
+    (emb * c).sum().backward()
+    out = dict(meta=np.asarray([32, 8, 41, 224]), emb=emb.detach().numpy(), c=c.numpy(),
+               grad_names=np.asarray([n for n, _ in net.named_parameters()]),
+               grad_norms=np.asarray([float(p.grad.norm()) for _, p in net.named_parameters()]))
+    for n, p in net.named_parameters():
+        out["grad/" + n] = _sample(p.grad.detach().numpy()).astype(np.float32)
+    for n, b in net.named_buffers():
+        if n.endswith("running_mean") and ("layer4" in n or n in ("bn1.running_mean", "features.running_mean")):
+            out["buf/" + n] = b.detach().numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "backbone_rstd.npz"), **out)
+    print("backbone_rstd.npz: emb", out["emb"].shape, "%d gradient tensors" % len(out["grad_names"]))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     if len(sys.argv) > 1 and sys.argv[1] == "schedulers":
         scheduler_vectors()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet_std":
+        resnet_std_vectors()
+        sys.exit(0)
+    resnet_std_vectors()
     scheduler_vectors()
     lru_traces()
     head_vectors()

@@ -321,3 +321,61 @@ def test_conv_batch_256_equals_small_batch_kernel_on_slices(cin, cout, k, stride
     for s0 in range(0, N, n):
         dw_sum += ops.conv2d_wgrad(dy[s0:s0 + n].contiguous(), x[s0:s0 + n].contiguous(), small).double()
     close(dw, dw_sum.float().cpu(), 1e-3)
+
+
+# ---- operators of the torchvision-style ResNet (reference model/resnet_std.py) ---------------------------------
+def test_stem7_im2col_matches_conv():
+    from vlsfr_amd import ops
+    torch.manual_seed(2)
+    N, H = 2, 36
+    x = torch.randn(N, 3, H, H)
+    w = bf(torch.randn(64, 3, 7, 7) * 0.05)
+    cols = ops.stem7_im2col(x.cuda())
+    assert float(cols.float()[:, 147:].abs().max()) == 0.0
+    wb, _ = ops.cast_weight(w.permute(0, 2, 3, 1).contiguous().cuda(), 64, 1, 147, Kp=160, transpose=False)
+    d = ops.ConvDesc(N, H // 2, H // 2, 160, 64, 1, 1, 1, 0)
+    y = ops.conv2d_fwd(cols, wb, d)
+    close(y.permute(0, 3, 1, 2), bf(F.conv2d(bf(x), w, None, 2, 3)), 1e-2)
+
+
+@pytest.mark.parametrize("N,H,C,ties", [(2, 14, 64, False), (3, 9, 16, True), (1, 112, 64, True)])
+def test_maxpool_fwd_bwd_matches_torch(N, H, C, ties):
+    """nn.MaxPool2d(3, 2, 1) (resnet_std.py:131) forward (exact) and backward: the gradient goes to the FIRST maximum of
+    a window — exercised with heavy ties (post-ReLU zeros, coarse values)."""
+    from vlsfr_amd import ops
+    torch.manual_seed(H + C)
+    x = torch.randn(N, C, H, H)
+    if ties:
+        x = torch.clamp((x * 2).round() / 2, min=0)             # many equal values and zeros
+    x = bf(x).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = bf(torch.randn_like(y))
+    y.backward(dy)
+    xg = nhwc(x.detach()).cuda().to(torch.bfloat16)
+    yg = ops.maxpool_fwd(xg)
+    assert torch.equal(yg.float().cpu(), nhwc(y.detach()))
+    dx = ops.maxpool_bwd(nhwc(dy).cuda().to(torch.bfloat16), xg, yg)
+    close(dx.permute(0, 3, 1, 2), bf(x.grad), 1e-2)            # sums of up to 4 bf16 values, rounded once
+
+
+def test_bn_relu_after_residual_and_relu_backward():
+    """Block ending of resnet_std.py:97-105: y = relu(bn(x) + identity), NHWC and flatten-order output, and its backward
+    mask dx = dy * (y > 0) (NCHW-ordered inputs for the last block)."""
+    from vlsfr_amd import ops
+    torch.manual_seed(5)
+    N, C, HW = 3, 64, 49
+    M = N * HW
+    x, res = bf(torch.randn(M, C)), bf(torch.randn(M, C))
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.1
+    want = F.relu(F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5) + res)
+    xg, rg = x.cuda().to(torch.bfloat16), res.cuda().to(torch.bfloat16)
+    sums = ops.bn_stats(xg, M, C)
+    y, _, _ = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), residual=rg, out_nchw=2)
+    close(y.view(M, C), bf(want), 1e-2)
+    y_nchw, _, _ = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), residual=rg, out_nchw=3)
+    assert torch.equal(y_nchw.view(N, C, HW).permute(0, 2, 1).reshape(M, C), y.view(M, C))
+    dy = bf(torch.randn(M, C)).cuda().to(torch.bfloat16)
+    dx = ops.relu_bwd(dy, y, M, C, HW)
+    assert torch.equal(dx.view(M, C), torch.where(y.view(M, C).float() > 0, dy, torch.zeros_like(dy)))
+    dy_nchw = dy.view(N, HW, C).permute(0, 2, 1).contiguous()
+    assert torch.equal(ops.relu_bwd(dy_nchw, y_nchw, M, C, HW, in_nchw=True), dx)

@@ -167,3 +167,34 @@ def test_schedulers_match_reference_values():
             else:
                 sch.update(None, float(it))
             assert abs(opt.param_groups[0]["lr"] - lr) <= 1e-12 * max(1.0, abs(lr)), (case["config"]["scheduler"], epoch, it)
+
+
+def build_rstd_oracle(z, dtype=torch.float64, emulate_bf16=False):
+    """The oracle's torchvision-style ResNet on the seeded state / images of tests/golden/backbone_rstd.npz."""
+    from oracle import backbones_ref as bb
+    D, B, seed, hw = [int(v) for v in z["meta"]]
+    sd0, _ = bb.make_backbone("rtiny", D)                    # names / shapes only; 224 x 224 -> fc is 2048 * 49 wide
+    sd0 = bb.resnet_std_state((1, 1, 1, 1), D, None, hw)
+    sd = common.fill_state(sd0, seed)
+    sd = {k: (v.to(dtype).requires_grad_(bb.trainable(k, "rtiny")) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    rng = np.random.default_rng(seed)
+    x = common.images_from_u8(common.synth_images_u8(rng, B, hw=hw)).to(dtype)
+    return sd, x, (lambda s, xx: bb.resnet_std_forward(s, xx, (1, 1, 1, 1), emulate_bf16))
+
+
+def test_resnet_std_oracle_matches_reference():
+    """The oracle's restatement of model/resnet_std.py (Bottleneck ResNet: 7x7/2 stem, max-pool, post-add ReLU, trainable
+    features.weight) against float64 outputs of the reference's own class: embeddings, every gradient norm, sampled
+    gradient tensors, BatchNorm running means."""
+    z = np.load(os.path.join(G, "backbone_rstd.npz"))
+    sd, x, fwd = build_rstd_oracle(z)
+    emb = fwd(sd, x)
+    (emb * torch.from_numpy(z["c"])).sum().backward()
+    np.testing.assert_allclose(emb.detach().numpy(), z["emb"], rtol=1e-9, atol=1e-12)
+    names = [str(n) for n in z["grad_names"]]
+    np.testing.assert_allclose([float(sd[n].grad.norm()) for n in names], z["grad_norms"], rtol=1e-7)
+    for key in z.files:
+        if key.startswith("grad/"):
+            np.testing.assert_allclose(sample(sd[key[5:]].grad.numpy()), z[key], rtol=1e-5, atol=1e-9)
+        elif key.startswith("buf/"):
+            np.testing.assert_allclose(sd[key[4:]].numpy(), z[key], rtol=1e-6, atol=1e-9)

@@ -230,7 +230,7 @@ def _emulated_oracle(net_type, D, Q, B, loss_type, margin, seed, layers, dtype):
     from oracle import ffc_ref
     o = ffc_ref.FFCRef(net_type, D, Q, 32.0, loss_type, margin, 0.99, layers=layers, dtype=dtype, emulate_bf16=True)
     sd = common.fill_state({k: v.detach() for k, v in o.probe.items()}, seed)
-    o.probe = {k: (v.to(dtype).requires_grad_(bb.trainable(k)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    o.probe = {k: (v.to(dtype).requires_grad_(bb.trainable(k, net_type)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     o.gallery = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     rng = np.random.default_rng(seed)
     o.queue = torch.from_numpy(common.unit_rows(rng, 2, Q, D)).to(dtype)
@@ -238,8 +238,9 @@ def _emulated_oracle(net_type, D, Q, B, loss_type, margin, seed, layers, dtype):
     ids = rng.choice(n_id, size=B // 2, replace=False)
     xl = torch.from_numpy(np.concatenate([ids, rng.integers(0, n_id, B - B // 2)]).astype(np.int64))
     yl = torch.from_numpy(np.concatenate([ids, rng.integers(0, n_id, B - B // 2)]).astype(np.int64))
-    x = common.images_from_u8(common.synth_images_u8(rng, B))
-    y = common.images_from_u8(common.synth_images_u8(rng, B))
+    hw = 64 if net_type == "rtiny" else 112
+    x = common.images_from_u8(common.synth_images_u8(rng, B, hw=hw))
+    y = common.images_from_u8(common.synth_images_u8(rng, B, hw=hw))
     return o, sd, x, y, xl, yl
 
 
@@ -258,12 +259,13 @@ def _emulated_pair(net_type, D, Q, B, loss_type, margin, seed, layers=None):
 # (net, feat_dim, pool slots, batch_size): the two backbones the bench runs (ir50 = BASELINE configs[1], ir100 = the
 # metric) at the batch the float64 oracle finishes in seconds, the 4-block iResNet and MobileFaceNet at batch 32.
 EMU_CASES = [("irtiny", 64, 512, 32, (1, 1, 1, 1)), ("mobile", 128, 1000, 32, None), ("ir50", 512, 2048, 8, None),
-             ("ir100", 512, 2048, 8, None)]
+             ("ir100", 512, 2048, 8, None), ("rtiny", 64, 512, 16, None)]
 # Absolute caps on top of the self-calibrated band below: loss, embedding cosine (>= 0.999 for bf16), relative
 # L2 of the whole gradient.  (The per-tensor bound is purely band-relative: a tensor's own band can be large where its
 # exact gradient is tiny.)
 EMU_CAP = {"irtiny": dict(loss=1e-3, cos=0.9995, g_all=5e-2), "mobile": dict(loss=2e-3, cos=0.999, g_all=0.35),
-           "ir50": dict(loss=5e-3, cos=0.999, g_all=0.2), "ir100": dict(loss=5e-3, cos=0.999, g_all=0.25)}
+           "ir50": dict(loss=5e-3, cos=0.999, g_all=0.2), "ir100": dict(loss=5e-3, cos=0.999, g_all=0.25),
+           "rtiny": dict(loss=2e-3, cos=0.999, g_all=0.2)}
 
 
 def _grad_errors(got, ref):
@@ -310,8 +312,8 @@ def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
     o32, _, _, _, _, _ = _emulated_oracle(net_type, D, Q, B, "Arc", 0.5, 31, layers, torch.float32)
     w32 = o32.forward(x, y, xl, yl)
     w32.backward()
-    ref = {k: v.grad.numpy() for k, v in o.probe.items() if bb.trainable(k)}
-    f32 = {k: v.grad.double().numpy() for k, v in o32.probe.items() if bb.trainable(k)}
+    ref = {k: v.grad.numpy() for k, v in o.probe.items() if bb.trainable(k, net_type)}
+    f32 = {k: v.grad.double().numpy() for k, v in o32.probe.items() if bb.trainable(k, net_type)}
     pn = dict(m.probe_net.named_parameters())
     got = {k: pn[k].grad.detach().double().cpu().numpy() for k in ref}
     noise_all, noise_each = _grad_errors(f32, ref)
@@ -330,13 +332,13 @@ def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
         assert e <= 2.0 * max(noise_each[k], noise_all, 2e-3), (k, e, noise_each[k], noise_all)
     # SGD-nesterov step + what the EMA made of the gallery net (the EMA ran inside forward, before the step)
     ps = o.parameters()
-    before = {k: v.detach().clone() for k, v in o.probe.items() if bb.trainable(k)}
+    before = {k: v.detach().clone() for k, v in o.probe.items() if bb.trainable(k, net_type)}
     ffc_ref.sgd_nesterov_step_ref(ps, [p.grad for p in ps], [None] * len(ps), 0.1)
     opt.step()
     torch.cuda.synchronize()
     num = den = 0.0
     for k, v in o.probe.items():
-        if bb.trainable(k):
+        if bb.trainable(k, net_type):
             gk = pn[k].detach().double().cpu().numpy()
             num += float(((gk - v.detach().numpy()) ** 2).sum())
             den += float(((v.detach() - before[k]).numpy() ** 2).sum())
@@ -397,3 +399,44 @@ def test_main_trains_from_a_face_store(tmp_path):
     net, loss = train(conf, log=lambda *_: None)
     assert np.isfinite(float(loss.detach()))
     assert len(net.lru.state_dict()) > 0 and max(k for k, _ in net.lru.state_dict()) < 40      # labels come from the kv file
+
+
+def test_resnet_std_backbone_matches_reference_golden():
+    """The torchvision-style ResNet executor (csrc/resnet.cpp; `--net_type r50` family) on the reference's own float64
+    outputs (tests/golden/backbone_rstd.npz: model/resnet_std.py ResNet(Bottleneck, [1,1,1,1]), eight 224 x 224 images):
+    embeddings by cosine, gradient norms and sampled gradient tensors within the bf16 band (calibrated like
+    test_step_vs_bf16_emulating_oracle: GPU vs the emulating oracle must sit on the fp32-vs-fp64 band)."""
+    from tests.test_oracle_golden import build_rstd_oracle
+    from vlsfr_amd.model.resnet_std import ResNet
+    z = np.load(os.path.join(G, "backbone_rstd.npz"))
+    D, B, seed, hw = [int(v) for v in z["meta"]]
+    sd, x, fwd = build_rstd_oracle(z, torch.float64, emulate_bf16=True)
+    net = ResNet([1, 1, 1, 1], feat_dim=D, image_size=hw)
+    net.load_state_dict({k: (v.detach().float() if v.is_floating_point() else v) for k, v in sd.items()})
+    net = net.cuda()
+    c = torch.from_numpy(z["c"])
+    emb = net(x.float().cuda())
+    (emb * c.float().cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert min_cos(emb.detach().cpu(), z["emb"]) >= 0.999                      # vs the reference itself (plain float64)
+    want = fwd(sd, x)
+    (want * c).sum().backward()
+    sd32, x32, fwd32 = build_rstd_oracle(z, torch.float32, emulate_bf16=True)
+    w32 = fwd32(sd32, x32)
+    (w32 * c.float()).sum().backward()
+    ref = {k: v.grad.numpy() for k, v in sd.items() if v.requires_grad}
+    f32 = {k: v.grad.double().numpy() for k, v in sd32.items() if v.requires_grad}
+    got = {k: p.grad.detach().double().cpu().numpy() for k, p in net.named_parameters()}
+    assert set(got) == set(ref)                                                 # features.weight trains here
+    noise_all, noise_each = _grad_errors(f32, ref)
+    g_all, g_each = _grad_errors(got, ref)
+    print("rstd: emb cos vs reference %.6f, gradient rel-L2 gpu %.2e (fp32-vs-fp64 band %.2e)" %
+          (min_cos(emb.detach().cpu(), z["emb"]), g_all, noise_all))
+    assert g_all <= max(1.5 * noise_all, 5e-3), (g_all, noise_all)
+    for k, e in g_each.items():
+        assert e <= 2.0 * max(noise_each[k], noise_all, 2e-3), (k, e, noise_each[k], noise_all)
+    # and against the reference's own gradient norms (plain float64: the bf16 band applies)
+    names = [str(n) for n in z["grad_names"]]
+    gn = np.asarray([float(np.linalg.norm(got[n])) for n in names])
+    big = z["grad_norms"] > 1e-2 * z["grad_norms"].max()
+    np.testing.assert_allclose(gn[big], z["grad_norms"][big], rtol=max(0.1, 4 * noise_all))

@@ -1323,10 +1323,11 @@ int run_igemm(ConvArgs a, hipStream_t st) {
   // ALGORITHMIC FLOPs of the convolution this launch implements (what bench.py's roofline may count):
   // the input gradient of a stride-2 layer visits every INPUT position, but 3/4 of its taps are the
   // zero rows of the dilated dY, so it is priced at the forward's output positions (= the positions of
-  // the gathered dY); the 32-channel 1x1 GEMM is the iResNet / MobileFaceNet stem on im2col rows,
-  // K = 27 real taps (3x3x3) padded to 32.
+  // the gathered dY); the 32- / 160-channel 1x1 GEMMs are the stems on im2col rows: K = 27 real taps (3x3x3,
+  // iResNet / MobileFaceNet) padded to 32, K = 147 (7x7x3, resnet_std) padded to 160.
   const double alg_pos = a.mode == 1 ? (double)a.Nimg * a.H * a.W : (double)P;
-  const double alg_k = (a.mode == 0 && a.C == 32 && a.R == 1 && a.S == 1) ? 27.0 : (double)a.R * a.S * a.C;
+  const double alg_k = (a.mode == 0 && a.R == 1 && a.S == 1 && (a.C == 32 || a.C == 160)) ? (a.C == 32 ? 27.0 : 147.0)
+                                                                                          : (double)a.R * a.S * a.C;
   ProfScope prof(st, 0, 2.0 * alg_pos * (double)a.Mrows * alg_k);
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
@@ -1563,7 +1564,8 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   dim3 grid(grid_x, (d->Cout + BM - 1) / BM, splitk);
   hipStream_t st = (hipStream_t)stream;
   // algorithmic FLOPs (the 32-channel 1x1 case is the stem on im2col rows: 27 real taps)
-  const double alg_k = (d->Cin == 32 && d->R == 1 && d->S == 1) ? 27.0 : (double)d->R * d->S * d->Cin;
+  const double alg_k = (d->R == 1 && d->S == 1 && (d->Cin == 32 || d->Cin == 160)) ? (d->Cin == 32 ? 27.0 : 147.0)
+                                                                                   : (double)d->R * d->S * d->Cin;
   ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * alg_k);
   const bool glds = g_wgrad_glds && d->Cin % 8 == 0 && d->Cout % 8 == 0 && (size_t)P * d->Cout < (1ull << 30) &&
                     (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30);

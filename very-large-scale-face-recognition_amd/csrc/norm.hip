@@ -170,10 +170,10 @@ struct BnApplyArgs {
 };
 
 // FLAGS (compile time, so that the streaming loop is one straight-line block): 1 PReLU, 2 residual,
-// 4 statistics of y, 8 flatten-order (NCHW) output
+// 4 statistics of y, 8 flatten-order (NCHW) output, 16 ReLU after the residual add (with 2; not with 1 / 4)
 template <int FLAGS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
-  constexpr bool PRELU = FLAGS & 1, RESID = FLAGS & 2, OSUMS = FLAGS & 4, NCHW = FLAGS & 8;
+  constexpr bool PRELU = FLAGS & 1, RESID = FLAGS & 2, OSUMS = FLAGS & 4, NCHW = FLAGS & 8, RELU_AFTER = FLAGS & 16;
   extern __shared__ float sh[];   // scale[C], shift[C]; reused by the output-statistics reduction
   const int C = a.C;
   const int tid = threadIdx.x;
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
           float z = xv[u].get(j) * sc[j] + sf[j];
           if (PRELU) z = z > 0.f ? z : z * sl[j];
           if (RESID) z += rs[u].get(j);
+          if (RELU_AFTER) z = z > 0.f ? z : 0.f;   // torchvision-style block: relu(bn(x) + identity), resnet_std.py:97-105
           o[j] = z;
         }
         const uint4 packed = pack8(o);
@@ -760,11 +761,15 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
                    float* out_sums, int32_t out_nchw, void* stream) {
   if (!x || !y || !sums || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_apply: bad argument");
+  const bool relu_after = (out_nchw & 2) != 0;   // bit 1 of out_nchw: y = relu(bn(x) + residual)
+  out_nchw &= 1;
+  if (relu_after && (!residual || slope || out_sums))
+    return fail(VLSFR_EINVAL, "vlsfr_bn_apply: relu-after-add needs a residual and neither PReLU nor output statistics");
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, sums, gamma, beta, slope, (const u16*)residual, save_mean,
                 save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw};
-  const int flags = (slope ? 1 : 0) | (residual ? 2 : 0) | (out_sums ? 4 : 0) | (out_nchw ? 8 : 0);
+  const int flags = (slope ? 1 : 0) | (residual ? 2 : 0) | (out_sums ? 4 : 0) | (out_nchw ? 8 : 0) | (relu_after ? 16 : 0);
   const dim3 grid(nblk), block(256);
   const size_t shb = 2 * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
@@ -772,6 +777,7 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
   switch (flags) {
     VLSFR_CASE(0) VLSFR_CASE(1) VLSFR_CASE(2) VLSFR_CASE(3) VLSFR_CASE(4) VLSFR_CASE(5) VLSFR_CASE(6) VLSFR_CASE(7)
     VLSFR_CASE(8) VLSFR_CASE(9) VLSFR_CASE(10) VLSFR_CASE(11) VLSFR_CASE(12) VLSFR_CASE(13) VLSFR_CASE(14) VLSFR_CASE(15)
+    VLSFR_CASE(18) VLSFR_CASE(26)
   }
 #undef VLSFR_CASE
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_apply");

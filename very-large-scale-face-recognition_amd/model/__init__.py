@@ -1,5 +1,5 @@
-"""Backbone registry — reference model/__init__.py:1-10 (`create_net`), extended with the deeper /
-shallower iResNets the reference defines but does not register (resnet_arcface.py:162-184)."""
+"""Backbone registry — reference model/__init__.py:1-10 (`create_net`: ir50 / r50 / mobile), extended with the deeper /
+shallower iResNets the reference defines but does not register (resnet_arcface.py:162-184) and two test-size nets."""
 from .. import _lib
 from .iresnet import IResNet, iresnet18, iresnet34, iresnet50, iresnet100, iresnet200
 
@@ -15,11 +15,17 @@ def _mobile(**kwargs):
 
 
 def _r50(**kwargs):
-    raise _lib.VlsfrError("net_type 'r50' (reference model/resnet_std.py) is outside the MI355X hot path of this "
-                          "build (SURVEY.md §2); use 'ir50' / 'ir100' / 'mobile'")
+    from .resnet_std import resnet50
+    return resnet50(**kwargs)
 
 
-net_creator = {'ir50': iresnet50, 'r50': _r50, 'mobile': _mobile,
+def _rtiny(**kwargs):
+    """One Bottleneck per stage at 64 x 64: the test-size member of the torchvision-style family."""
+    from .resnet_std import ResNet
+    return ResNet([1, 1, 1, 1], image_size=64, **kwargs)
+
+
+net_creator = {'ir50': iresnet50, 'r50': _r50, 'mobile': _mobile, 'rtiny': _rtiny,
                'irtiny': _irtiny, 'ir18': iresnet18, 'ir34': iresnet34, 'ir100': iresnet100, 'ir200': iresnet200}
 
 

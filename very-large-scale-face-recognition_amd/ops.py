@@ -147,3 +147,34 @@ def embed_bwd(demb, emb, saved, gamma, dbeta, dfc_bias, dgamma=None):
     _call("vlsfr_embed_bwd", _p(demb), _p(emb), _p(inv_norm), _p(xhat), _p(invstd), _p(gamma), _p(dz), _p(dfc),
           _p(dbeta), _p(dfc_bias), _p(dgamma), ctypes.c_int32(B), ctypes.c_int32(D), _st())
     return dfc
+
+
+# ---- torchvision-style ResNet operators (csrc/resnet_ops.hip; include/vlsfr.h section 7c) -------------------
+def stem7_im2col(x_nchw):
+    N, _, H, W = x_nchw.shape
+    Ho, Wo = out_hw(H, 7, 2, 3), out_hw(W, 7, 2, 3)
+    out = torch.empty(N * Ho * Wo, 160, dtype=torch.bfloat16, device=x_nchw.device)
+    _call("vlsfr_stem7_im2col", _p(x_nchw), _p(out), ctypes.c_int32(N), ctypes.c_int32(H), ctypes.c_int32(W), _st())
+    return out
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    y = torch.empty(N, out_hw(H, 3, 2, 1), out_hw(W, 3, 2, 1), C, dtype=torch.bfloat16, device=x.device)
+    _call("vlsfr_maxpool3x3s2_fwd", _p(x), _p(y), ctypes.c_int32(N), ctypes.c_int32(H), ctypes.c_int32(W), ctypes.c_int32(C), _st())
+    return y
+
+
+def maxpool_bwd(dy, x, y):
+    N, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    _call("vlsfr_maxpool3x3s2_bwd", _p(dy), _p(x), _p(y), _p(dx), ctypes.c_int32(N), ctypes.c_int32(H), ctypes.c_int32(W),
+          ctypes.c_int32(C), _st())
+    return dx
+
+
+def relu_bwd(dy, y, M, C, HW, in_nchw=False):
+    dx = torch.empty(M * C, dtype=torch.bfloat16, device=dy.device)
+    _call("vlsfr_relu_bwd_bf16", _p(dy), _p(y), _p(dx), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW),
+          ctypes.c_int32(int(in_nchw)), _st())
+    return dx
