@@ -71,11 +71,11 @@ def parse():
     return ap.parse_args()
 
 
-def synth_batch(rng, B, n_id, device):
+def synth_batch(rng, B, n_id, device, hw=112):
     """uniform uint8 pixels -> (v - 127.5) * 0.0078125 fp32 NCHW; id half shares labels
     between the two views, instance half draws them independently (main.py:53-60)."""
     def imgs():
-        u8 = torch.from_numpy(rng.integers(0, 256, size=(B, 3, 112, 112), dtype=np.uint8)).to(device)
+        u8 = torch.from_numpy(rng.integers(0, 256, size=(B, 3, hw, hw), dtype=np.uint8)).to(device)
         return (u8.float() - 127.5) * 0.0078125
     h = B // 2
     ids = rng.choice(n_id, size=h, replace=False)
@@ -84,14 +84,14 @@ def synth_batch(rng, B, n_id, device):
     return imgs(), imgs(), torch.from_numpy(xl), torch.from_numpy(yl)
 
 
-def _cpu_steps(o, B, n_id, steps, tag):
+def _cpu_steps(o, B, n_id, steps, tag, hw=112):
     """Times `steps` oracle steps (zero_grad -> forward -> backward -> SGD-nesterov) after one warm-up step."""
     from oracle import ffc_ref
     rng = np.random.default_rng(0)
     bufs = [None] * len(o.parameters())
     t_total, faces = 0.0, 0
     for step in range(steps + 1):
-        x, y, xl, yl = synth_batch(rng, B, n_id, "cpu")
+        x, y, xl, yl = synth_batch(rng, B, n_id, "cpu", hw)
         note("cpu baseline %s step %d" % (tag, step))
         t0 = time.perf_counter()
         for p in o.parameters():
@@ -120,7 +120,7 @@ def cpu_baseline(args):
     gen = torch.Generator().manual_seed(0)
     o = ffc_ref.FFCRef(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, gen=gen)
     o.lru.restore([(k, k) for k in range(4096)])          # a few thousand resident identities (O(n) oracle LRU)
-    value = _cpu_steps(o, B, 4096, args.cpu_steps, args.net)
+    value = _cpu_steps(o, B, 4096, args.cpu_steps, args.net, 224 if args.net in ("r50", "r101") else (64 if args.net == "rtiny" else 112))
     out = dict(value=value, unit="faces/sec", cores=threads, kind="port",
                sample="%s D=%d, pool 131072 slots, batch_size %d, %d timed steps after 1 warm-up, fp32 PyTorch-CPU oracle" %
                       (args.net, args.feat, B, args.cpu_steps))
@@ -192,7 +192,8 @@ def main():
     sched.update(0, 0.0)
     rng = np.random.default_rng(1234 + rank)
     B = args.batch
-    batches = [synth_batch(rng, B, args.identities, dev) for _ in range(min(4, args.steps + args.warmup))]
+    hw = model.probe_net.image_size                          # 112 (iResNet / MobileFaceNet), 224 for r50
+    batches = [synth_batch(rng, B, args.identities, dev, hw) for _ in range(min(4, args.steps + args.warmup))]
 
     def one_step(i):
         x, y, xl, yl = batches[i % len(batches)]
@@ -318,8 +319,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
-                               "(2 x %d faces per step per GPU), SGD-nesterov, 112x112 synthetic images" %
-                               (args.net, args.identities, Q, args.feat, args.loss, B, B),
+                               "(2 x %d faces per step per GPU), SGD-nesterov, %dx%d synthetic images" %
+                               (args.net, args.identities, Q, args.feat, args.loss, B, B, hw, hw),
                    "parallelism": ("dp%d" % world) + ("" if world == 1 else "+zero1-sgd+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")),
                    "loss": loss_val},
         "roofline": roofline,
