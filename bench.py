@@ -295,7 +295,7 @@ def main():
         # the class matmul north_star singles out: MFMA fraction of both contractions (4 B Q D FLOPs per sweep) and
         # the HBM rate of the pool bytes it streams (bf16 shadow: Q * D * 2 per sweep)
         pool_bytes = Q // max(world if sharded else 1, 1) * args.feat * 2
-        roofline["other"]["head_sweep_kernel"].update(
+        (roofline if dom == "head_sweep_kernel" else roofline["other"]["head_sweep_kernel"]).update(
             avg_launch_us=round(hs[0] * 1e3 / hs[2], 1), mfma_frac=round(hs[1] / (hs[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             pool_gb_per_s=round(pool_bytes * hs[2] / (hs[0] * 1e-3) / 1e9, 1))
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be collected from inside this
