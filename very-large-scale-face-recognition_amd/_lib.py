@@ -80,6 +80,10 @@ def lib():
         import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
+        # A/B switches from the environment, e.g. VLSFR_OPTIONS="head_variant=2,conv_glds=3" (vlsfr_set_option)
+        for kv in filter(None, os.environ.get("VLSFR_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            check(_lib.vlsfr_set_option(k.strip().encode(), c_int32(int(v))), "vlsfr_set_option(%s)" % kv)
     return _lib
 
 

@@ -1156,7 +1156,7 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
 namespace vlsfr {
 int head_set_option(const char* name, int32_t value) {
   if (!strcmp(name, "head_variant")) {
-    if (value < -1 || value > 2) return fail(VLSFR_EINVAL, "head_variant must be -1 (auto), 0, 1 or 2");
+    if (value < -1 || value > 1) return fail(VLSFR_EINVAL, "head_variant must be -1 (auto), 0 or 1");
     g_head_variant = value;
     return VLSFR_OK;
   }

@@ -12,10 +12,15 @@
 //     ds_read_b64_tr_b16 block reads bank-conflict free; rows past the chunk end are out of range for
 //     the buffer descriptor and arrive as zeros.  Two tiles (66 KB) are in flight per CU behind a
 //     counted s_waitcnt vmcnt, one raw s_barrier per tile.
-//   * RB = 2: a wave owns 32 probe rows (two 16-row MFMA blocks) with P in registers (128 VGPRs) and
-//     O in 256 accumulator registers, one wave per SIMD — every W fragment read from LDS feeds two
-//     MFMAs in both products: 0.5 KiB of LDS per MFMA, the LDS pipe is half busy at the MFMA rate.
-//     RB = 1 (batch <= 64): 16 rows per wave; that case is HBM-bound.
+//   * a wave owns 16 probe rows with P in registers (64 VGPRs) and O in 128 accumulator registers.  Batch <= 64: four
+//     waves per workgroup, one per SIMD (HBM-bound: 6.0 TB/s of bf16 pool measured).  Larger batches: EIGHT waves per
+//     workgroup = 128 rows on ONE LDS ring, two waves per SIMD, so that the softmax, the LDS latencies and the LDS-DMA
+//     issue of one wave run under the MFMAs of its SIMD partner (1104 TFLOP/s = 0.44 of the bf16 MFMA peak at batch
+//     256, 10 M x 512 pool; the 4-wave form of the same code: 824).  A 32-rows-per-wave form (RB = 2: every W fragment
+//     feeds two MFMAs, half the LDS bytes per MFMA) was built with asm-owned accumulators a[0:255] (hipcc cannot place
+//     256 accumulators + 128 registers of P: it spills P) and measured SLOWER (5.45 ms vs 4.98 ms per sweep): with one
+//     wave per SIMD nothing hides that wave's own 8 LDS-DMA issues, softmax and LDS waits per tile, which is what
+//     the two-waves-per-SIMD form buys; it is not in the tree.
 //   * all LDS reads of the loop are inline asm behind counted lgkmcnt waits (the compiler would put a
 //     vmcnt(0) in front of any LDS read it can see while a DMA is pending and drain the ring).
 //   * hard-negative candidates (rows with label -1, ffc.py:86-90): a lane keeps only the admission
@@ -366,13 +371,12 @@ size_t sweep16_lds_bytes(int chunk_cols) { return (size_t)NS * TILE_B + (size_t)
 int sweep16_rows_per_wg(int variant) { return variant == 0 ? 64 : 128; }
 
 int launch_sweep16(const Sweep16Args& a, int variant, bool topk, bool sv, hipStream_t st) {
-  if (variant < 0 || variant > 2) return fail(VLSFR_EINVAL, "head_sweep16: variant must be 0, 1 or 2");
+  if (variant < 0 || variant > 1) return fail(VLSFR_EINVAL, "head_sweep16: variant must be 0 or 1");
   if (a.chunk_cols % TQ != 0 || a.chunk_cols / TQ > SW16_MAX_TILES || a.n_chunks % 8 != 0 ||
       a.Bp != a.n_rowblk * sweep16_rows_per_wg(variant))
     return fail(VLSFR_EINVAL, "head_sweep16: inconsistent plan (chunk_cols %d, n_chunks %d, Bp %d)", a.chunk_cols, a.n_chunks, a.Bp);
   if (variant == 0) return launch_v<4, 1>(a, topk, sv, st);
-  if (variant == 1) return launch_v<8, 1>(a, topk, sv, st);
-  return launch_v<4, 2>(a, topk, sv, st);
+  return launch_v<8, 1>(a, topk, sv, st);
 }
 
 }  // namespace vlsfr

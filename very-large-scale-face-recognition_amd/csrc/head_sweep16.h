@@ -36,7 +36,6 @@ struct Sweep16Args {
 // variant 0: 4 waves x 16 rows (64 probe rows per workgroup, one wave per SIMD) — batch <= 64, HBM-bound;
 // variant 1: 8 waves x 16 rows (128 rows per workgroup, two waves per SIMD sharing one LDS ring: the softmax and
 //            the LDS latencies of one wave run under the MFMAs of its SIMD partner);
-// variant 2: 4 waves x 32 rows (128 rows, one wave per SIMD, every W fragment feeds two MFMAs) — experimental.
 // grid = n_chunks * n_rowblk workgroups, Bp = n_rowblk * sweep16_rows_per_wg(variant).
 int launch_sweep16(const Sweep16Args& a, int variant, bool topk, bool sv, hipStream_t st);
 int sweep16_rows_per_wg(int variant);
