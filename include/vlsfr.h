@@ -421,6 +421,9 @@ void vlsfr_profile_enable(int32_t on);
  * 0 = register-staged kernel) */
 int vlsfr_set_option(const char* name, int32_t value);
 int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops, int64_t* launches);
+/* what an empty event bracket reads on `stream` (microseconds, mean of 64): the per-launch overhead contained in the
+ * totals above; synchronises the stream (measurement support only) */
+double vlsfr_profile_event_overhead_us(void* stream);
 /* Diagnostics: device buffer of 2 x 64 x 8 int64 receiving per-phase shader-clock stamps of one workgroup of
  * the ping-pong convolution variant (scripts/conv_trace.py); nullptr switches the stamps off. */
 int vlsfr_conv_trace(void* device_buffer);

@@ -1,19 +1,21 @@
 #!/bin/bash
-# Round-end evidence: kernel-trace stats of bench.py (serial and concurrent) and the PMC traffic passes.
-# Writes under gpurun_out/prof_$1/ (copy what should be judged into profiles/).
+# Round evidence for the metric's own configuration (bench.py defaults: ir100 + 10 485 760 identities, batch_size 256):
+# kernel-trace stats of bench.py (single stream and the three-stream schedule) and the two PMC traffic passes
+# (FETCH_SIZE, WRITE_SIZE in separate runs with nothing but --pmc: see MI355X_MICROARCH.md, HBM / rocprofv3 sections).
+# Writes under gpurun_out/prof_$1/ (copy what should be judged into profiles/).   usage: profile_round.sh <tag>
 tag=$1
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o s -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial > $O/serial.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial > $O/serial.log 2>&1
 cp /tmp/ks/s_kernel_stats.csv $O/bench_serial_kernel_stats.csv; grep "^{" $O/serial.log > $O/bench_serial_profiled.json
 echo "serial trace done"
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kc -o c -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/conc.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kc -o c -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/conc.log 2>&1
 cp /tmp/kc/c_kernel_stats.csv $O/bench_concurrent_kernel_stats.csv; grep "^{" $O/conc.log > $O/bench_concurrent_profiled.json
 echo "concurrent trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > $O/pmc_fetch.log 2>&1
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > $O/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > $O/pmc_write.log 2>&1
 echo "write pass done"
-python $R/scripts/pmc_traffic.py /tmp/pf/f_counter_collection.csv /tmp/pw/w_counter_collection.csv $O/pmc_traffic.json ir50 256 1048576
+python3 $R/scripts/pmc_traffic.py /tmp/pf/f_counter_collection.csv /tmp/pw/w_counter_collection.csv $O/pmc_traffic.json ir100 256 10485760

@@ -1458,6 +1458,29 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
   return VLSFR_OK;
 }
 
+// Mean elapsed time (microseconds) between two events recorded back to back on `stream` with nothing in between: what a
+// ProfScope bracket reads on top of the kernel's own duration.  bench.py subtracts it per launch.
+double vlsfr_profile_event_overhead_us(void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int N = 64;
+  hipEvent_t a[N], b[N];
+  for (int i = 0; i < N; ++i)
+    if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return 0.0;
+  for (int i = 0; i < N; ++i) {
+    (void)hipEventRecord(a[i], st);
+    (void)hipEventRecord(b[i], st);
+  }
+  (void)hipStreamSynchronize(st);
+  double sum = 0.0;
+  for (int i = 0; i < N; ++i) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, a[i], b[i]) == hipSuccess) sum += t;
+    (void)hipEventDestroy(a[i]);
+    (void)hipEventDestroy(b[i]);
+  }
+  return sum / N * 1e3;
+}
+
 void vlsfr_profile_reset(void) {
   for (auto& r : vlsfr::g_prof) {
     (void)hipEventDestroy(r.a);
