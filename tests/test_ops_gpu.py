@@ -379,3 +379,20 @@ def test_bn_relu_after_residual_and_relu_backward():
     assert torch.equal(dx.view(M, C), torch.where(y.view(M, C).float() > 0, dy, torch.zeros_like(dy)))
     dy_nchw = dy.view(N, HW, C).permute(0, 2, 1).contiguous()
     assert torch.equal(ops.relu_bwd(dy_nchw, y_nchw, M, C, HW, in_nchw=True), dx)
+
+
+@pytest.mark.parametrize("rows,taps,C", [(128, 9, 64), (512, 1, 25088), (64, 1, 27), (96, 9, 64), (256, 9, 32)])
+def test_weight_cast_and_transpose(rows, taps, C):
+    """bf16 operand copies of a weight: w[rows][taps*C] rounded, and wT[c][tap][row] (the dgrad operand) — the tiled
+    LDS-transpose path (rows, C multiples of 64) and the element-wise path (stem, odd shapes), bit for bit."""
+    from vlsfr_amd import ops
+    torch.manual_seed(rows + taps + C)
+    Kp = 32 if C == 27 else taps * C
+    w = torch.randn(rows, taps, C).cuda()
+    wb, wT = ops.cast_weight(w, rows, taps, C, Kp=Kp, transpose=C != 27)
+    want = w.to(torch.bfloat16)
+    assert torch.equal(wb.view(rows, Kp)[:, :taps * C], want.view(rows, taps * C))
+    if Kp > taps * C:
+        assert float(wb.view(rows, Kp)[:, taps * C:].float().abs().max()) == 0.0
+    if wT is not None:
+        assert torch.equal(wT.view(C, taps, rows), want.permute(2, 1, 0).contiguous())
