@@ -229,6 +229,13 @@ int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT,
 /* splitk <= 0: library choice */
 int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
                        void* stream);
+/* The same with a workspace of vlsfr_conv2d_wgrad_workspace_bytes(d, splitk) bytes: the split-K slices are written
+ * to fp32 slabs with plain stores and summed in a fixed order by a second launch (one atomic per element of dw
+ * instead of splitk: the atomics were 30-45 % of the kernel), which also makes the weight gradient reproducible run
+ * to run.  workspace NULL / too small, or a single slice: the atomic path above. */
+size_t vlsfr_conv2d_wgrad_workspace_bytes(const vlsfr_conv_desc* d, int32_t splitk);
+int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 5b. Depthwise convolutions (device).  Replaces nn.Conv2d(groups = C) of MobileFaceNet

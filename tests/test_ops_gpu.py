@@ -396,3 +396,26 @@ def test_weight_cast_and_transpose(rows, taps, C):
         assert float(wb.view(rows, Kp)[:, taps * C:].float().abs().max()) == 0.0
     if wT is not None:
         assert torch.equal(wT.view(C, taps, rows), want.permute(2, 1, 0).contiguous())
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,hw,N", [(256, 256, 3, 1, 14, 32), (64, 64, 3, 1, 56, 4), (128, 256, 1, 2, 28, 8),
+                                                  (32, 64, 1, 1, 40, 2), (512, 512, 3, 2, 14, 16)])
+def test_wgrad_slab_path_is_deterministic_and_matches_atomics(cin, cout, k, stride, hw, N):
+    """Split-K weight gradient through workspace slabs + ordered reduction (vlsfr_conv2d_wgrad_ws): equals the atomic
+    path up to fp32 summation order, accumulates into an existing gradient, and — unlike fp32 atomics in arrival
+    order — is bit-identical run to run."""
+    from vlsfr_amd import ops
+    pad = 1 if k == 3 else 0
+    ho = (hw + 2 * pad - k) // stride + 1
+    gen = torch.Generator(device="cuda").manual_seed(cin + hw)
+    x = torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16)
+    dy = torch.randn(N, ho, ho, cout, device="cuda", generator=gen).to(torch.bfloat16)
+    d = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad)
+    ref = ops.conv2d_wgrad(dy, x, d)
+    a, nbytes = ops.conv2d_wgrad_ws(dy, x, d)
+    b, _ = ops.conv2d_wgrad_ws(dy, x, d)
+    close(a, ref.cpu(), 1e-4)
+    if nbytes > 0:
+        assert torch.equal(a, b)                                # deterministic
+    c, _ = ops.conv2d_wgrad_ws(dy, x, d, dw=a.clone())
+    close(c, (2 * ref).cpu(), 1e-4)

@@ -65,6 +65,7 @@ int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // "conv_glds": 0 register-staged
 int g_use_halo = 0;          // "conv_halo": halo-patch kernel for 3x3 / stride-1 layers: 0 never (no end-to-end gain measured), 1 the 64-channel layers, 2 all
 int g_wgrad_glds = 1;        // "wgrad_glds": 1 LDS-DMA ring (conv_wgrad_glds_kernel), 0 register-staged kernel
 int g_wgrad_kt = 32;         // "wgrad_kt": pixels per k-tile of the register-staged weight-gradient kernel (32 or 64)
+int g_wgrad_slabs = 1;       // "wgrad_slabs": 1 = split-K slices to workspace slabs + ordered reduction when a workspace is given, 0 = fp32 atomics
 int g_wgrad_target = 384;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
@@ -901,6 +902,8 @@ struct WgradArgs {
   int splitk;
   int n_coltiles;    // column tiles per tap = ceil(C / BN)
   int dbg;           // diagnostics (vlsfr_set_option conv_dbg): 1 skips the epilogue atomics, 2 the k loop
+  float* partial;    // or nullptr: [splitk][Cout][R][S][C] fp32 slabs, slice blockIdx.z written with plain stores and
+                     // summed by wgrad_reduce_kernel in a fixed order (deterministic; 1 atomic per element instead of splitk)
 };
 
 template <int BM, int BN, int KT>
@@ -1043,7 +1046,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = c0 + wn * (BN / 2) + j * 16 + r16;
-        if (c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+        if (c < a.C) {
+          if (a.partial) a.partial[(size_t)blockIdx.z * a.Cout * K + (size_t)m * K + tap * a.C + c] = acc[i][j][e];
+          else atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+        }
       }
     }
   }
@@ -1257,11 +1263,60 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = c0 + wn * (BN / 2) + j * 16 + r16;
-        if (TPT > 1 || c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+        if (TPT > 1 || c < a.C) {
+          if (a.partial) a.partial[(size_t)blockIdx.z * a.Cout * K + (size_t)m * K + tap * a.C + c] = acc[i][j][e];
+          else atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+        }
       }
     }
   }
 #endif
+}
+
+inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
+// dw[i] += sum_z partial[z][i], z in a fixed order: the split-K weight gradient without splitk atomics per element.
+// The final add stays atomic — the two backward passes of a step may run on two streams into the same gradient — but
+// with exactly two contributions into a zeroed buffer the result does not depend on their order (a + b == b + a).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, float* dw, int64_t n4, int64_t n, int splitk) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 s = ((const f32x4*)partial)[i];
+    for (int z = 1; z < splitk; ++z) {
+      const f32x4 v = *(const f32x4*)(partial + (size_t)z * n + 4 * i);
+      s += v;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(dw + 4 * i + e, s[e]);
+  }
+}
+
+struct WgradPlan {
+  int KT, nkt, BM, BN, grid_x, tiles, splitk, n_coltiles;
+  bool row3;
+};
+WgradPlan wgrad_plan(const vlsfr_conv_desc* d, int splitk) {
+  WgradPlan w;
+  const int Ho = out_dim(d->H, d->R, d->stride, d->pad), Wo = out_dim(d->W, d->S, d->stride, d->pad);
+  const int P = d->N * Ho * Wo;
+  w.KT = g_wgrad_glds ? 64 : g_wgrad_kt;
+  w.nkt = (P + w.KT - 1) / w.KT;
+  const bool wide = d->Cin >= 128;
+  w.BM = d->Cout >= 128 ? 128 : 64;
+  // 64 -> 64 channel 3x3 layers: one column tile = the three taps of a filter row (LDS-DMA kernel only)
+  w.row3 = g_wgrad_glds && d->Cin == 64 && w.BM == 64 && d->R == 3 && d->S == 3;
+  w.BN = w.row3 ? 192 : wide ? 128 : 64;
+  w.n_coltiles = w.row3 ? 1 : (d->Cin + w.BN - 1) / w.BN;
+  w.grid_x = w.row3 ? 3 : w.n_coltiles * d->R * d->S;
+  w.tiles = w.grid_x * ((d->Cout + w.BM - 1) / w.BM);
+  if (splitk <= 0) {   // aim at g_wgrad_target workgroups, >= 8 k-tiles each
+    splitk = (g_wgrad_target + w.tiles - 1) / w.tiles;
+    if (splitk > w.nkt / 8) splitk = w.nkt / 8;
+    if (splitk < 1) splitk = 1;
+  }
+  // no empty slice: every z of the grid owns at least one k-tile (the slab path sums all of them)
+  const int per = (w.nkt + splitk - 1) / splitk;
+  w.splitk = (w.nkt + per - 1) / per;
+  return w;
 }
 
 int conv_check(const vlsfr_conv_desc* d, const char* who) {
@@ -1276,7 +1331,6 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
   return VLSFR_OK;
 }
 
-inline int out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
 template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false, bool SWP = false>
 int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
@@ -1416,6 +1470,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
     g_wgrad_kt = value == 64 ? 64 : 32;
     return VLSFR_OK;
   }
+  if (name && !strcmp(name, "wgrad_slabs")) {
+    g_wgrad_slabs = value;
+    return VLSFR_OK;
+  }
   if (name && !strcmp(name, "wgrad_target_wgs")) {
     g_wgrad_target = value > 0 ? value : 384;
     return VLSFR_OK;
@@ -1546,8 +1604,19 @@ int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT,
   return run_igemm(a, (hipStream_t)stream);
 }
 
+size_t vlsfr_conv2d_wgrad_workspace_bytes(const vlsfr_conv_desc* d, int32_t splitk) {
+  if (conv_check(d, "vlsfr_conv2d_wgrad_workspace_bytes")) return 0;
+  const WgradPlan w = wgrad_plan(d, splitk);
+  return w.splitk > 1 ? (size_t)w.splitk * d->Cout * d->R * d->S * d->Cin * sizeof(float) : 0;
+}
+
 int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
                        void* stream) {
+  return vlsfr_conv2d_wgrad_ws(d, dy, x, dw, splitk, nullptr, 0, stream);
+}
+
+int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   int rc = conv_check(d, "vlsfr_conv2d_wgrad");
   if (rc) return rc;
   if (!dy || !x || !dw) return fail(VLSFR_EINVAL, "vlsfr_conv2d_wgrad: null buffer");
@@ -1567,22 +1636,15 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   a.stride = d->stride;
   a.pad = d->pad;
   const int P = a.Nimg * a.Ho * a.Wo;
-  const int KT = g_wgrad_glds ? 64 : g_wgrad_kt;
-  const int nkt = (P + KT - 1) / KT;
-  const bool wide = d->Cin >= 128;
-  const int BM = d->Cout >= 128 ? 128 : 64;
-  // 64 -> 64 channel 3x3 layers: one column tile = the three taps of a filter row (LDS-DMA kernel only)
-  const bool row3 = g_wgrad_glds && d->Cin == 64 && BM == 64 && d->R == 3 && d->S == 3;
-  const int BN = row3 ? 192 : wide ? 128 : 64;
-  a.n_coltiles = row3 ? 1 : (d->Cin + BN - 1) / BN;
-  const int grid_x = row3 ? 3 : a.n_coltiles * d->R * d->S;
-  const int tiles = grid_x * ((d->Cout + BM - 1) / BM);
-  if (splitk <= 0) {   // aim at g_wgrad_target workgroups (each adds its whole tile with fp32 atomics), >= 8 k-tiles each
-    splitk = (g_wgrad_target + tiles - 1) / tiles;
-    if (splitk > nkt / 8) splitk = nkt / 8;
-    if (splitk < 1) splitk = 1;
-  }
+  const WgradPlan w = wgrad_plan(d, splitk);
+  const int KT = w.KT, BM = w.BM, BN = w.BN, grid_x = w.grid_x;
+  splitk = w.splitk;
+  a.n_coltiles = w.n_coltiles;
   a.splitk = splitk;
+  const size_t n_dw = (size_t)d->Cout * d->R * d->S * d->Cin;
+  const size_t need = (size_t)splitk * n_dw * sizeof(float);
+  // slab path: enough workspace, more than one slice, 16-byte granularity of the reduction
+  a.partial = (workspace && splitk > 1 && workspace_bytes >= need && n_dw % 4 == 0 && g_wgrad_slabs) ? (float*)workspace : nullptr;
   a.dbg = g_conv_dbg;
   dim3 grid(grid_x, (d->Cout + BM - 1) / BM, splitk);
   hipStream_t st = (hipStream_t)stream;
@@ -1623,6 +1685,13 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   else VLSFR_WGRAD(64, 64);
 #undef VLSFR_WGRAD
   VLSFR_HIP_CHECK_LAUNCH("conv_wgrad launch");
+  if (a.partial) {
+    const int64_t n4 = (int64_t)n_dw / 4;
+    const int64_t blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, a.partial, dw, n4,
+                       (int64_t)n_dw, splitk);
+    VLSFR_HIP_CHECK_LAUNCH("conv_wgrad reduce launch");
+  }
   return VLSFR_OK;
 }
 

@@ -69,6 +69,7 @@ struct vlsfr_iresnet {
   size_t sums_begin, sums_end, red_begin, red_end;
   size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0;
   size_t max_act = 0;   // largest activation tensor in bytes
+  size_t wgrad_ws = 0;  // split-K slabs of the largest weight gradient (vlsfr_conv2d_wgrad_ws)
 
   size_t take_ctx(size_t bytes) {
     size_t o = ctx_bytes;
@@ -214,9 +215,20 @@ int build(vlsfr_iresnet* n) {
   n->off_feat_invstd = n->take_ctx((size_t)n->D * 4);
   n->off_emb = n->take_ctx((size_t)B * n->D * 4);
   n->off_invnorm = n->take_ctx((size_t)B * 4);
-  // scratch: 3 activation-sized gradient buffers + the shortcut tensor + small fp32 scratch
+  auto ws_of = [&](const Conv& c) {
+    const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&c.d, 0);
+    if (w > n->wgrad_ws) n->wgrad_ws = w;
+  };
+  ws_of(n->stem);
+  for (auto& b : n->blocks) {
+    ws_of(b.conv1);
+    ws_of(b.conv2);
+    if (b.has_ds) ws_of(b.convd);
+  }
+  ws_of(n->fc);
+  // scratch: 3 activation-sized gradient buffers + the shortcut tensor + small fp32 scratch + the wgrad slabs
   n->scratch_bytes = 4 * align_up(n->max_act) + align_up((size_t)3 * 2048 * 4) + align_up((size_t)64 * 32 * 4) +
-                     align_up((size_t)B * n->D * 4) + align_up((size_t)B * n->D * 2);
+                     align_up((size_t)B * n->D * 4) + align_up((size_t)B * n->D * 2) + align_up(n->wgrad_ws);
   return VLSFR_OK;
 }
 
@@ -227,6 +239,7 @@ struct Scratch {
   float* stem_dw;
   float* dz;
   char* dfc;
+  void* wgrad_ws;
 };
 
 Scratch carve(const vlsfr_iresnet* n, void* scratch) {
@@ -243,6 +256,8 @@ Scratch carve(const vlsfr_iresnet* n, void* scratch) {
   s.dz = (float*)p;
   p += align_up((size_t)n->B * n->D * 4);
   s.dfc = p;
+  p += align_up((size_t)n->B * n->D * 2);
+  s.wgrad_ws = p;
   return s;
 }
 
@@ -406,7 +421,7 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd),
                       params[n->p_feat_w], sc.dz, sc.dfc, grads[n->p_feat_b], grads[n->p_fc_b], nullptr, B, n->D, st));
-  RUN(vlsfr_conv2d_wgrad(&n->fc.d, sc.dfc, ctx + n->off_flat, grads[n->fc.p_w], 0, st));
+  RUN(vlsfr_conv2d_wgrad_ws(&n->fc.d, sc.dfc, ctx + n->off_flat, grads[n->fc.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
   char* dflat = sc.g[0];
   RUN(vlsfr_conv2d_dgrad(&n->fc.d, sc.dfc, wc + n->fc.off_wT, dflat, st));
   char* dcur = sc.g[1];
@@ -425,15 +440,15 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
     const char* dout = sc.g[cur_i];
     // main branch
     RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
-    RUN(vlsfr_conv2d_wgrad(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, st));
+    RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
     RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st));   // d c1
-    RUN(vlsfr_conv2d_wgrad(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, st));
+    RUN(vlsfr_conv2d_wgrad_ws(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, st));                 // d a1 (in t2)
     const char* add = dout;
     if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
       RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
-      RUN(vlsfr_conv2d_wgrad(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, st));
+      RUN(vlsfr_conv2d_wgrad_ws(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
       add = sc.idn;
     }
@@ -452,7 +467,7 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
                   ctx, st));
   hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e));
-  RUN(vlsfr_conv2d_wgrad(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, st));
+  RUN(vlsfr_conv2d_wgrad_ws(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
   RUN(vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, st));
   return signal(4);
 }

@@ -49,7 +49,7 @@ struct vlsfr_mobilenet {
   size_t l1_wb, l1_wT;
   size_t off_cols, off_fc, off_z, off_xhat, off_invstd, off_emb, off_invnorm, off_zero_bias;
   size_t sums_begin, sums_end, red_begin, red_end;
-  size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0, max_act = 0;
+  size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0, max_act = 0, wgrad_ws = 0;
   size_t take_ctx(size_t b) {
     size_t o = ctx_bytes;
     ctx_bytes += align_up(b);
@@ -157,8 +157,17 @@ int build(vlsfr_mobilenet* n) {
   n->off_invnorm = n->take_ctx((size_t)n->B * 4);
   // scratch: per-unit output gradients are needed until their producers have run (residual fan-out),
   // so keep one gradient buffer per "live" tensor: 4 rotating buffers + small fp32 areas
+  for (const auto& u : n->units)
+    if (u.kind != DW) {
+      const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&u.d, 0);   // split-K slabs (vlsfr_conv2d_wgrad_ws)
+      if (w > n->wgrad_ws) n->wgrad_ws = w;
+    }
+  {
+    const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&n->l1d, 0);
+    if (w > n->wgrad_ws) n->wgrad_ws = w;
+  }
   n->scratch_bytes = 4 * align_up(n->max_act) + align_up((size_t)64 * 32 * 4) + align_up((size_t)n->B * n->D * 4) +
-                     align_up((size_t)n->B * n->D * 2);
+                     align_up((size_t)n->B * n->D * 2) + align_up(n->wgrad_ws);
   return VLSFR_OK;
 }
 
@@ -167,6 +176,7 @@ struct Scratch {
   float* stem_dw;
   float* dz;
   char* dfc;
+  void* wgrad_ws;
 };
 Scratch carve(const vlsfr_mobilenet* n, void* scratch) {
   Scratch s;
@@ -179,6 +189,8 @@ Scratch carve(const vlsfr_mobilenet* n, void* scratch) {
   s.dz = (float*)p;
   p += align_up((size_t)n->B * n->D * 4);
   s.dfc = p;
+  p += align_up((size_t)n->B * n->D * 2);
+  s.wgrad_ws = p;
   return s;
 }
 
@@ -276,7 +288,7 @@ int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const 
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_invstd), params[n->l1_g], sc.dz,
                       sc.dfc, grads[n->l1_b], nullptr, grads[n->l1_g], n->B, n->D, st));
-  RUN(vlsfr_conv2d_wgrad(&n->l1d, sc.dfc, ctx + l7.a, grads[n->l1_w], 0, st));
+  RUN(vlsfr_conv2d_wgrad_ws(&n->l1d, sc.dfc, ctx + l7.a, grads[n->l1_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
   // gradient buffers: `cur` = d(output of unit k); a residual source keeps its extra gradient in
   // `pend` until the walk reaches it (the bottleneck input is consumed 3 units later).
   int cur = 0;
@@ -317,13 +329,13 @@ int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const 
     if (u.kind == STEM) {
       e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
       if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward: memset: %s", hipGetErrorString(e));
-      RUN(vlsfr_conv2d_wgrad(&u.d, dc, ctx + n->off_cols, sc.stem_dw, 0, st));
+      RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_unpad_add(sc.stem_dw, grads[u.p_w], 64, 32, 27, st));
       break;
     }
     char* din = sc.g[t2];
     if (u.kind == PW) {
-      RUN(vlsfr_conv2d_wgrad(&u.d, dc, in, grads[u.p_w], 0, st));
+      RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, in, grads[u.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_conv2d_dgrad(&u.d, dc, wc + u.off_wT, din, st));
     } else {
       RUN(vlsfr_dwconv_wgrad(&u.d, dc, in, grads[u.p_w], st));

@@ -53,7 +53,7 @@ struct vlsfr_resnet {
   int p_fc_b, p_feat_w, p_feat_b, run_feat;
   size_t off_fcout, off_z, off_xhat, off_feat_invstd, off_emb, off_invnorm;
   size_t sums_begin, sums_end, red_begin, red_end;
-  size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0, max_act = 0;
+  size_t ctx_bytes = 0, wcache_bytes = 0, scratch_bytes = 0, max_act = 0, wgrad_ws = 0;
 
   size_t take_ctx(size_t bytes) {
     size_t o = ctx_bytes;
@@ -183,8 +183,20 @@ int build(vlsfr_resnet* n) {
   n->off_emb = n->take_ctx((size_t)B * n->D * 4);
   n->off_invnorm = n->take_ctx((size_t)B * 4);
   // scratch: 4 activation-sized gradient buffers + the shortcut tensor of the forward pass + small fp32 areas
+  auto ws_of = [&](const Conv& c) {
+    const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&c.d, 0);   // split-K slabs (vlsfr_conv2d_wgrad_ws)
+    if (w > n->wgrad_ws) n->wgrad_ws = w;
+  };
+  ws_of(n->stem);
+  for (auto& b : n->blocks) {
+    ws_of(b.conv1);
+    ws_of(b.conv2);
+    ws_of(b.conv3);
+    if (b.has_ds) ws_of(b.convd);
+  }
+  ws_of(n->fc);
   n->scratch_bytes = 5 * align_up(n->max_act) + align_up((size_t)2048 * 4) + align_up((size_t)64 * 160 * 4) +
-                     align_up((size_t)B * n->D * 4) + align_up((size_t)B * n->D * 2);
+                     align_up((size_t)B * n->D * 4) + align_up((size_t)B * n->D * 2) + align_up(n->wgrad_ws);
   return VLSFR_OK;
 }
 
@@ -195,6 +207,7 @@ struct Scratch {
   float* stem_dw;
   float* dz;
   char* dfc;
+  void* wgrad_ws;
 };
 Scratch carve(const vlsfr_resnet* n, void* scratch) {
   Scratch s;
@@ -210,6 +223,8 @@ Scratch carve(const vlsfr_resnet* n, void* scratch) {
   s.dz = (float*)p;
   p += align_up((size_t)n->B * n->D * 4);
   s.dfc = p;
+  p += align_up((size_t)n->B * n->D * 2);
+  s.wgrad_ws = p;
   return s;
 }
 
@@ -351,7 +366,7 @@ int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float*
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd), params[n->p_feat_w], sc.dz,
                       sc.dfc, grads[n->p_feat_b], grads[n->p_fc_b], grads[n->p_feat_w], B, n->D, st));
-  RUN(vlsfr_conv2d_wgrad(&n->fc.d, sc.dfc, ctx + lastb.out, grads[n->fc.p_w], 0, st));
+  RUN(vlsfr_conv2d_wgrad_ws(&n->fc.d, sc.dfc, ctx + lastb.out, grads[n->fc.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
   int cur = 0;   // index of the buffer holding d(out of block k)
   RUN(vlsfr_conv2d_dgrad(&n->fc.d, sc.dfc, wc + n->fc.off_wT, sc.g[cur], st));   // [n][c][hw] order, like the saved output
   for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
@@ -367,18 +382,18 @@ int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float*
     RUN(vlsfr_relu_bwd_bf16(sc.g[cur], ctx + b.out, dte, Mout, b.cout, b.Ho * b.Ho, last ? 1 : 0, st));
     char* u = sc.g[cur];   // d(out) is consumed: its buffer is free again
     RUN(bn_backward(n, b.bn3, dte, ctx + b.c3, t[1], Mout, b.Ho * b.Ho, 0, params, grads, ctx, sc.dslope, st));       // d c3
-    RUN(vlsfr_conv2d_wgrad(&b.conv3.d, t[1], ctx + b.a2, grads[b.conv3.p_w], 0, st));
+    RUN(vlsfr_conv2d_wgrad_ws(&b.conv3.d, t[1], ctx + b.a2, grads[b.conv3.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv3.d, t[1], wc + b.conv3.off_wT, t[2], st));                                          // d a2
     RUN(bn_backward(n, b.bn2, t[2], ctx + b.c2, t[1], Mout, b.Ho * b.Ho, 1, params, grads, ctx, sc.dslope, st));        // d c2
-    RUN(vlsfr_conv2d_wgrad(&b.conv2.d, t[1], ctx + b.a1, grads[b.conv2.p_w], 0, st));
+    RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t[1], ctx + b.a1, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t[1], wc + b.conv2.off_wT, t[2], st));                                          // d a1
     RUN(bn_backward(n, b.bn1, t[2], ctx + b.c1, t[1], Min, b.H * b.H, 1, params, grads, ctx, sc.dslope, st));           // d c1
-    RUN(vlsfr_conv2d_wgrad(&b.conv1.d, t[1], x_in, grads[b.conv1.p_w], 0, st));
+    RUN(vlsfr_conv2d_wgrad_ws(&b.conv1.d, t[1], x_in, grads[b.conv1.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t[1], wc + b.conv1.off_wT, t[2], st));                                          // d in (main)
     const char* other = dte;                                                                                           // identity branch
     if (b.has_ds) {
       RUN(bn_backward(n, b.bnd, dte, ctx + b.cs, t[1], Mout, b.Ho * b.Ho, 0, params, grads, ctx, sc.dslope, st));       // d cs
-      RUN(vlsfr_conv2d_wgrad(&b.convd.d, t[1], x_in, grads[b.convd.p_w], 0, st));
+      RUN(vlsfr_conv2d_wgrad_ws(&b.convd.d, t[1], x_in, grads[b.convd.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_conv2d_dgrad(&b.convd.d, t[1], wc + b.convd.off_wT, u, st));
       other = u;
     }
@@ -395,7 +410,7 @@ int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float*
                   sc.dslope, st));
   hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 160 * 4, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_resnet_backward: memset: %s", hipGetErrorString(e));
-  RUN(vlsfr_conv2d_wgrad(&n->stem.d, t[1], ctx + n->off_cols, sc.stem_dw, 0, st));
+  RUN(vlsfr_conv2d_wgrad_ws(&n->stem.d, t[1], ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
   return vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 160, 147, st);
 }
 

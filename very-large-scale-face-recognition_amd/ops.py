@@ -178,3 +178,16 @@ def relu_bwd(dy, y, M, C, HW, in_nchw=False):
     _call("vlsfr_relu_bwd_bf16", _p(dy), _p(y), _p(dx), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW),
           ctypes.c_int32(int(in_nchw)), _st())
     return dx
+
+
+def conv2d_wgrad_ws(dy, x, desc, dw=None, splitk=0):
+    """Weight gradient through the slab path (split-K slices to a workspace, ordered reduction)."""
+    if dw is None:
+        dw = torch.zeros(desc.Cout, desc.R, desc.S, desc.Cin, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    L.vlsfr_conv2d_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    n = L.vlsfr_conv2d_wgrad_workspace_bytes(ctypes.byref(desc), ctypes.c_int32(splitk))
+    ws = torch.empty(max(n, 16), dtype=torch.uint8, device=x.device)
+    _call("vlsfr_conv2d_wgrad_ws", ctypes.byref(desc), _p(dy), _p(x), _p(dw), ctypes.c_int32(splitk), _p(ws),
+          ctypes.c_size_t(n), _st())
+    return dw, n
