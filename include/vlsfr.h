@@ -231,8 +231,9 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
                        void* stream);
 /* The same with a workspace of vlsfr_conv2d_wgrad_workspace_bytes(d, splitk) bytes: the split-K slices are written
  * to fp32 slabs with plain stores and summed in a fixed order by a second launch (one atomic per element of dw
- * instead of splitk: the atomics were 30-45 % of the kernel), which also makes the weight gradient reproducible run
- * to run.  workspace NULL / too small, or a single slice: the atomic path above. */
+ * instead of splitk), which makes the weight gradient bit-reproducible run to run.  Selected by
+ * vlsfr_set_option("wgrad_slabs", 1); the default stays the atomic path (measured faster: 605 vs 532 TFLOP/s).
+ * workspace NULL / too small, or a single slice: the atomic path as well. */
 size_t vlsfr_conv2d_wgrad_workspace_bytes(const vlsfr_conv_desc* d, int32_t splitk);
 int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
                           void* workspace, size_t workspace_bytes, void* stream);

@@ -400,11 +400,14 @@ def test_weight_cast_and_transpose(rows, taps, C):
 
 @pytest.mark.parametrize("cin,cout,k,stride,hw,N", [(256, 256, 3, 1, 14, 32), (64, 64, 3, 1, 56, 4), (128, 256, 1, 2, 28, 8),
                                                   (32, 64, 1, 1, 40, 2), (512, 512, 3, 2, 14, 16)])
-def test_wgrad_slab_path_is_deterministic_and_matches_atomics(cin, cout, k, stride, hw, N):
+def test_wgrad_slab_path_is_deterministic_and_matches_atomics(cin, cout, k, stride, hw, N, request):
     """Split-K weight gradient through workspace slabs + ordered reduction (vlsfr_conv2d_wgrad_ws): equals the atomic
     path up to fp32 summation order, accumulates into an existing gradient, and — unlike fp32 atomics in arrival
     order — is bit-identical run to run."""
-    from vlsfr_amd import ops
+    import ctypes
+    from vlsfr_amd import _lib, ops
+    _lib.lib().vlsfr_set_option(b"wgrad_slabs", ctypes.c_int32(1))
+    request.addfinalizer(lambda: _lib.lib().vlsfr_set_option(b"wgrad_slabs", ctypes.c_int32(0)))
     pad = 1 if k == 3 else 0
     ho = (hw + 2 * pad - k) // stride + 1
     gen = torch.Generator(device="cuda").manual_seed(cin + hw)

@@ -65,7 +65,9 @@ int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // "conv_glds": 0 register-staged
 int g_use_halo = 0;          // "conv_halo": halo-patch kernel for 3x3 / stride-1 layers: 0 never (no end-to-end gain measured), 1 the 64-channel layers, 2 all
 int g_wgrad_glds = 1;        // "wgrad_glds": 1 LDS-DMA ring (conv_wgrad_glds_kernel), 0 register-staged kernel
 int g_wgrad_kt = 32;         // "wgrad_kt": pixels per k-tile of the register-staged weight-gradient kernel (32 or 64)
-int g_wgrad_slabs = 1;       // "wgrad_slabs": 1 = split-K slices to workspace slabs + ordered reduction when a workspace is given, 0 = fp32 atomics
+int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace slabs + ordered reduction (bit-reproducible weight gradients),
+                             // 0 = fp32 atomics (default: measured 605 vs 532 TFLOP/s at ir100 / batch 256 — the slab stores are 64-byte
+                             // row segments, no cheaper than the atomics they replace, and the reduction is a second launch)
 int g_wgrad_target = 384;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
