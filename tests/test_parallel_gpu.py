@@ -144,3 +144,62 @@ def test_two_rank_step_on_one_gpu():
         assert rel(res[1][mode]["w"], res[0][mode]["w"]) < 1e-6          # parameters stay replicated
         assert res[1][mode]["lru"] == res[0][mode]["lru"] and res[1][mode]["qp"] == res[0][mode]["qp"]
         assert np.array_equal(res[1][mode]["pool"], res[0][mode]["pool"])
+
+
+def _train_worker(rank, port, out, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK="0")
+    import faulthandler
+    logdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(logdir, exist_ok=True)
+    trace = open(os.path.join(logdir, "two_rank_train%d.log" % rank), "w")
+    faulthandler.dump_traceback_later(200, repeat=False, file=trace, exit=True)
+    try:
+        from vlsfr_amd.main import parse_args, train
+        base = ["--net_type", "irtiny", "--feat_dim", "32", "--queue_size", "64", "--batch_size", "8", "--print_freq", "2",
+                "--iters_per_epoch", "4", "--num_class", "500", "--dist_backend", "gloo"]
+        res = {}
+        for tag, extra in (("a", []), ("b", ["--resume", os.path.join(tmp, "a", "1.pt")])):
+            net, loss = train(parse_args(base + ["--saved_dir", os.path.join(tmp, tag)] + extra), log=lambda *_: None)
+            torch.cuda.synchronize()
+            trace.write("run %s done\n" % tag)
+            trace.flush()
+            res[tag] = dict(loss=float(loss.detach()), lru=net.lru.state_dict(), qp=net._state().qp.tolist(),
+                            shard=net.queue.cpu().numpy(), w=net.probe_net.state_dict()["layer1.0.conv1.weight"].float().cpu().numpy())
+        res["files"] = sorted(os.listdir(os.path.join(tmp, "a")))
+        out.put((rank, res))
+        faulthandler.cancel_dump_traceback_later()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_rank_training_driver_checkpoints_shard_wise_and_resumes(tmp_path):
+    """main.train with WORLD_SIZE = 2 (gloo, one GPU): pool built shard-local, ZeRO-1 optimizer, shard-wise checkpoint
+    files (rank 0: model + allocator with fc = None; every rank: its pool slots), and `--resume` from them continues to
+    the state of the uninterrupted run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, port, out, str(tmp_path))) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=300) for _ in range(WORLD))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0]["files"] == ["1.pool0.pt", "1.pool1.pt", "1.pt", "2.pool0.pt", "2.pool1.pt", "2.pt"]
+    ck = torch.load(os.path.join(str(tmp_path), "a", "1.pt"), weights_only=True)
+    assert ck["fc"] is None and len(ck["qp"]) == 64
+    rel = lambda u, v: float(np.linalg.norm(u - v) / (np.linalg.norm(v) + 1e-30))
+    for r in range(WORLD):
+        a, b = res[r]["a"], res[r]["b"]
+        assert a["shard"].shape == (2, 32, 32)                               # each rank holds Q / 2 slots only
+        assert a["lru"] == b["lru"] and a["qp"] == b["qp"]
+        assert abs(a["loss"] - b["loss"]) <= 2e-2 * abs(a["loss"])
+        assert float(np.abs(a["shard"] - b["shard"]).max()) < 0.05
+        assert rel(b["w"], a["w"]) < 2e-2
+    assert rel(res[1]["a"]["w"], res[0]["a"]["w"]) < 1e-6

@@ -70,23 +70,38 @@ def save_checkpoint(path, ffc_net, pool, optimizer=None, real_iter=0):
                            'optimizer': optimizer.state_dict() if optimizer is not None else None}}, path)
 
 
-def load_checkpoint(path, ffc_net, optimizer=None):
+def load_checkpoint(path, ffc_net, optimizer=None, step_model=None):
     """Resume (the reference only saves): weights, pool, LRU order via LRU.restore (lru.py:113) and
     queue positions.  A checkpoint written by the reference itself (no `resume` key) restarts the gallery net
-    as a copy of the probe net, as FFC.__init__ does (ffc.py:53-55).  Returns the iteration to continue from."""
+    as a copy of the probe net, as FFC.__init__ does (ffc.py:53-55).  With an identity-sharded `step_model` the pool
+    comes from this rank's `<name>.pool<rank>.pt` beside `path` (what a sharded run writes), or — for a file that
+    holds the whole pool (`fc`) — from this rank's slot range of it.  Returns the iteration to continue from."""
     ck = torch.load(path, map_location="cpu", weights_only=True)
     ffc_net.probe_net.load_state_dict(ck['state_dict'])
     extra = ck.get('resume') or {}
     ffc_net.gallery_net.load_state_dict(extra.get('gallery_state_dict') or ck['state_dict'])
-    with torch.no_grad():
-        ffc_net.queue.copy_(ck['fc'].to(ffc_net.queue.device))
-    state = ffc_net._state()
-    state.lru.reset()
-    state.lru.restore([tuple(kv) for kv in ck['lru']])
-    qp = ck['qp']
-    state.qp[:] = np.asarray([qp[i] for i in range(len(qp))], dtype=np.uint8)
+    sharded = step_model is not None and hasattr(step_model, 'load_pool_state')
+    if ck.get('fc') is None:
+        if not sharded:
+            raise ValueError("%s holds no pool (written by a sharded run): resume it with the same number of ranks" % path)
+        shard_file = '%s.pool%d.pt' % (path[:-3] if path.endswith('.pt') else path, step_model.rank)
+        step_model.load_pool_state(torch.load(shard_file, map_location="cpu", weights_only=True))
+    else:
+        with torch.no_grad():
+            if sharded:
+                Qs = step_model.head.queue.shape[1]
+                step_model.head.queue.copy_(ck['fc'][:, step_model.rank * Qs:(step_model.rank + 1) * Qs])
+            else:
+                ffc_net.queue.copy_(ck['fc'].to(ffc_net.queue.device))
+        state = ffc_net._state()
+        state.lru.reset()
+        state.lru.restore([tuple(kv) for kv in ck['lru']])
+        qp = ck['qp']
+        state.qp[:] = np.asarray([qp[i] for i in range(len(qp))], dtype=np.uint8)
     if optimizer is not None and extra.get('optimizer') is not None:
         optimizer.load_state_dict(extra['optimizer'])
+        if hasattr(optimizer, 'scatter_state'):
+            optimizer.scatter_state()
     return int(extra.get('real_iter', 0))
 
 
@@ -147,10 +162,15 @@ def train(conf, log=print):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if not dist.is_initialized():
+            backend = getattr(conf, "dist_backend", "nccl")            # "gloo": rehearsal on one GPU (tests), host-staged
+            dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     torch.manual_seed(0)
+    sharded = world > 1 and conf.queue_size % world == 0 and getattr(conf, 'pool', 'sharded') == 'sharded'
     ffc_net = FFC(conf.net_type, conf.feat_dim, conf.queue_size, conf.scale, conf.loss_type, conf.margin, conf.alpha,
-                  conf.neg_margin, conf.pretrained_model_path, conf.num_class).cuda()          # main.py:116-117
+                  conf.neg_margin, conf.pretrained_model_path, conf.num_class,           # main.py:116-117
+                  pool_device=dev if world > 1 else None,                                # N > 1: no rank ever builds or
+                  pool_shard=(int(os.environ.get("RANK", "0")), world) if sharded else None).cuda()   # holds the whole pool
     optim_config = load_config(conf.optim_config) if conf.optim_config else dict(OPTIM_CONFIG)
     step_model = ffc_net
     start_iter = 0
@@ -159,9 +179,6 @@ def train(conf, log=print):
         # reference's interface around the partitioned optimizer
         from .parallel import DataParallelFFC, ShardedFFC
         from .optim.optimizer import WarmupSchedule
-        if getattr(conf, "resume", ""):
-            start_iter = load_checkpoint(conf.resume, ffc_net, None)   # before the pool is sharded over the ranks
-        sharded = conf.queue_size % world == 0
         step_model = ShardedFFC(ffc_net, dist) if sharded else DataParallelFFC(ffc_net, dist)
         if optim_config['optim'] != 'SGD' or optim_config['scheduler'] == 'ReduceLROnPlateau':
             raise ValueError("multi-GPU runs use the partitioned SGD with a warm-up schedule")
@@ -178,6 +195,8 @@ def train(conf, log=print):
             hyper = dict(gamma=optim_config['gamma'])
         lr_scheduler = WarmupSchedule(optim, optim_config['scheduler'], optim_config.get('warmup', 0),
                                       optim_config.get('epochs', 1), **hyper)
+        if getattr(conf, "resume", ""):
+            start_iter = load_checkpoint(conf.resume, ffc_net, optim, step_model)
     else:
         optim, lr_scheduler = get_optim_scheduler([p for p in ffc_net.parameters() if p.requires_grad], optim_config)
         if getattr(conf, "resume", ""):
@@ -224,6 +243,9 @@ def parse_args(argv=None):
     conf.add_argument('--data_store', type=str, default='', help='comma-separated FaceStore directories (data.py; the reference '
                       'hard-codes its LMDB paths at main.py:168-169); empty = synthetic batches')
     conf.add_argument('--data_kv', type=str, default='', help='the kv files of --data_store ("<key> <label>" lines)')
+    conf.add_argument('--dist_backend', type=str, default='nccl', choices=['nccl', 'gloo'])
+    conf.add_argument('--pool', type=str, default='sharded', choices=['sharded', 'replicated'],
+                      help='N > 1: identity-sharded pool (default) or a full replica per rank')
     conf.add_argument('--resume', type=str, default='', help='checkpoint written by this driver (or by the reference) to continue from')
     return conf.parse_args(argv)
 
