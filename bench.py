@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
+    ap.add_argument("--phases", action="store_true", help="diagnostic: print the forward / backward / update split to stderr")
+    ap.add_argument("--timed-profile", action="store_true", help="per-launch HIP events inside the timed region itself (they cost "
+                    "~1.5 %% of the step: by default the K timed steps run clean and are REPEATED with the events on)")
     ap.add_argument("--opt", action="append", default=[], help="name=value tuning switch (vlsfr_set_option), repeatable")
     ap.add_argument("--conv-glds", type=int, default=-1, help="A/B switch for the conv kernel variant (vlsfr_set_option)")
     ap.add_argument("--pool", default="sharded", choices=["sharded", "replicated"],
@@ -195,14 +198,26 @@ def main():
     hw = model.probe_net.image_size                          # 112 (iResNet / MobileFaceNet), 224 for r50
     batches = [synth_batch(rng, B, args.identities, dev, hw) for _ in range(min(4, args.steps + args.warmup))]
 
-    def one_step(i):
+    phase_ev = []
+
+    def one_step(i, phases=False):
         x, y, xl, yl = batches[i % len(batches)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phases else None
+        if phases:
+            ev[0].record()
         opt.zero_grad()
         loss = step_model(x, y, xl, yl)
+        if phases:
+            ev[1].record()
         loss.backward()
         if world > 1:
             step_model.reduce_gradients(opt)
+        if phases:
+            ev[2].record()
         opt.step()
+        if phases:
+            ev[3].record()
+            phase_ev.append(ev)
         return loss
 
     L = _lib.lib()
@@ -218,8 +233,14 @@ def main():
         note("warm-up step %d done" % i)
     if dist is not None:
         dist.barrier()
+    if args.phases:          # diagnostic: forward / backward / update split of the three-stream schedule (main-stream events)
+        for i in range(4):
+            one_step(args.warmup + i, phases=True)
+        torch.cuda.synchronize()
+        for k, nm in enumerate(("forward (2 passes + heads)", "backward (2 passes)", "optimizer + EMA")):
+            note("phase %-28s %.2f ms" % (nm, sum(e[k].elapsed_time(e[k + 1]) for e in phase_ev[1:]) / (len(phase_ev) - 1)))
     L.vlsfr_profile_reset()
-    L.vlsfr_profile_enable(1)
+    L.vlsfr_profile_enable(1 if args.timed_profile else 0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     host_ms = []
@@ -255,6 +276,14 @@ def main():
 
     L.vlsfr_profile_event_overhead_us.restype = ctypes.c_double
     ev_us = float(L.vlsfr_profile_event_overhead_us(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    if not args.timed_profile:
+        # `value` comes from K clean steps; the same schedule is repeated with a HIP-event bracket around every launch of
+        # the three contraction families on its own stream (roofline.timed_region)
+        L.vlsfr_profile_enable(1)
+        for i in range(min(args.steps, 5)):
+            one_step(args.warmup + i)
+        torch.cuda.synchronize()
+        L.vlsfr_profile_enable(0)
     fams_timed = collect()
     # Per-kernel rate: in the timed region two or three HIP streams share the CUs, so a launch's event
     # duration includes the time it shared the chip with another kernel.  The roofline figure is taken
@@ -291,9 +320,10 @@ def main():
                     avg_launch_us=round(ms * 1e3 / max(n, 1), 2), event_bracket_us_subtracted=round(ev_us, 2),
                     measured_in=("timed region (single stream)" if not serial_steps else
                                  "serialized replay of %d steps after the timed region (one stream)" % serial_steps),
-                    timed_region=dict(achieved=round(tfl / (tms * 1e-3) / 1e12, 2) if tms > 0 else 0.0,
-                                      avg_launch_us=round(tms * 1e3 / max(tn, 1), 2), launches=int(tn),
-                                      note="streams overlap: launch durations include shared-chip time"),
+                    timed_region=None if tn == 0 else dict(
+                        achieved=round(tfl / (tms * 1e-3) / 1e12, 2) if tms > 0 else 0.0,
+                        avg_launch_us=round(tms * 1e3 / max(tn, 1), 2), launches=int(tn),
+                        note="the timed schedule repeated with HIP events on every launch; streams overlap: launch durations include shared-chip time"),
                     other={k: dict(total_ms=round(v[0], 2), tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                                    launches=int(v[2])) for k, v in fams.items() if k != dom})
     hs = fams.get("head_sweep_kernel")

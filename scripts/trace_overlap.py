@@ -25,3 +25,24 @@ for s, e, n in sel:
     agg[k][0] += e - s; agg[k][1] += 1
 for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:22]:
     print("%-62s %8.3f ms/step %6d calls/step avg %.1f us" % (k, d / 3e6, c // 3, d / c / 1e3))
+
+# classes: contraction kernels (MFMA-bound) vs everything else (HBM- / latency-bound)
+def is_mfma(n):
+    return any(t in n for t in ("conv_igemm", "conv_wgrad", "head_sweep"))
+pts = []
+for s, e, n in sel:
+    c = 0 if is_mfma(n) else 1
+    pts.append((s, c, 1)); pts.append((e, c, -1))
+pts.sort()
+d = [0, 0]; last = None
+t_m = t_o = t_both = t_m2 = 0
+for t, c, dd in pts:
+    if last is not None:
+        dt = t - last
+        if d[0] and d[1]: t_both += dt
+        elif d[0]: t_m += dt
+        elif d[1]: t_o += dt
+        if d[0] >= 2: t_m2 += dt
+    d[c] += dd; last = t
+print("per step: contraction kernels only %.2f ms, contraction + other %.2f, other only %.2f, idle %.2f; >= 2 contraction kernels %.2f" %
+      (t_m / 3e6, t_both / 3e6, t_o / 3e6, (wall - t_m - t_both - t_o) / 3e6, t_m2 / 3e6))

@@ -68,7 +68,8 @@ int g_wgrad_kt = 32;         // "wgrad_kt": pixels per k-tile of the register-st
 int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace slabs + ordered reduction (bit-reproducible weight gradients),
                              // 0 = fp32 atomics (default: measured 605 vs 532 TFLOP/s at ir100 / batch 256 — the slab stores are 64-byte
                              // row segments, no cheaper than the atomics they replace, and the reduction is a second launch)
-int g_wgrad_target = 384;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
+int g_wgrad_round_up = 0;    // "wgrad_round_up": 1 = round the slice count up (may exceed wgrad_target_wgs), the round-1 rule
+int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
@@ -1339,8 +1340,8 @@ WgradPlan wgrad_plan(const vlsfr_conv_desc* d, int splitk) {
   w.n_coltiles = w.row3 ? 1 : (d->Cin + w.BN - 1) / w.BN;
   w.grid_x = w.row3 ? 3 : w.n_coltiles * d->R * d->S;
   w.tiles = w.grid_x * ((d->Cout + w.BM - 1) / w.BM);
-  if (splitk <= 0) {   // aim at g_wgrad_target workgroups, >= 8 k-tiles each
-    splitk = (g_wgrad_target + w.tiles - 1) / w.tiles;
+  if (splitk <= 0) {   // at most g_wgrad_target workgroups (never a second round: one more slice than fits costs a third), >= 8 k-tiles each
+    splitk = g_wgrad_round_up ? (g_wgrad_target + w.tiles - 1) / w.tiles : g_wgrad_target / w.tiles;
     if (splitk > w.nkt / 8) splitk = w.nkt / 8;
     if (splitk < 1) splitk = 1;
   }
@@ -1483,6 +1484,10 @@ extern "C" {
 void vlsfr_profile_enable(int32_t on) { vlsfr::g_prof_on = on != 0; }
 
 int vlsfr_set_option(const char* name, int32_t value) {
+  if (name && !strcmp(name, "wgrad_round_up")) {
+    g_wgrad_round_up = value != 0;
+    return VLSFR_OK;
+  }
   if (name && !strcmp(name, "xcd_map")) {
     g_xcd_map = value != 0;
     return VLSFR_OK;
@@ -1516,7 +1521,7 @@ int vlsfr_set_option(const char* name, int32_t value) {
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "wgrad_target_wgs")) {
-    g_wgrad_target = value > 0 ? value : 384;
+    g_wgrad_target = value > 0 ? value : 512;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "bn_block_kb")) {
