@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (block-scaled v_mfma_scale_*_f8f6f4 forms), same table
 
 
 def host_threads():
@@ -59,6 +60,10 @@ def parse():
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="A/B: weight gradients of each backward pass on a side stream "
+                    "(vlsfr_iresnet_backward_overlap; measured slower, off by default)")
+    ap.add_argument("--head-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the e4m3 sweep of csrc/head8.hip (config C5's "
+                    "precision for the class matmul; the backbone stays bf16)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: print the forward / backward / update split to stderr")
     ap.add_argument("--timed-profile", action="store_true", help="per-launch HIP events inside the timed region itself (they cost "
                     "~1.5 %% of the step: by default the K timed steps run clean and are REPEATED with the events on)")
@@ -173,9 +178,13 @@ def main():
     # ffc.py:29-30); under the identity-sharded pool every rank builds only its own slots
     model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, pool_device=dev,
                 pool_shard=(rank, world) if sharded else None).cuda()
+    model.__dict__['head_dtype'] = args.head_dtype
     if args.serial:
         model.__dict__['concurrent_streams'] = False
         model.probe_net.concurrent_backward = False
+        model.probe_net.overlap_wgrad = False
+    elif args.overlap_wgrad:
+        model.probe_net.overlap_wgrad = True
     n_res = min(Q, args.identities)
     ar = np.arange(n_res)
     model.lru.restore_arrays(ar.astype(np.int64), ar.astype(np.int32))   # steady state: the pool is full (lru.py:113)
@@ -294,6 +303,7 @@ def main():
     if serial_steps:
         model.__dict__['concurrent_streams'] = False
         model.probe_net.concurrent_backward = False
+        model.probe_net.overlap_wgrad = False
         one_step(0)
         torch.cuda.synchronize()
         L.vlsfr_profile_enable(1)
@@ -304,6 +314,7 @@ def main():
         fams = collect()
         model.__dict__['concurrent_streams'] = True
         model.probe_net.concurrent_backward = True
+        model.probe_net.overlap_wgrad = args.overlap_wgrad
     loss_val = float(step_model.global_loss(loss)) if world > 1 else float(loss.detach())   # collective: every rank
     if rank != 0:
         return
@@ -315,8 +326,10 @@ def main():
     ms, fl, n = fams[dom]
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     tms, tfl, tn = fams_timed[dom]
-    roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, launches=int(n),
+    head_peak = PEAK_FP8_TFLOPS if args.head_dtype == "fp8" else PEAK_BF16_TFLOPS      # the sweep's MFMA form
+    dom_peak = head_peak if dom == "head_sweep_kernel" else PEAK_BF16_TFLOPS
+    roofline = dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=dom_peak, unit="TFLOP/s",
+                    frac=round(achieved / dom_peak, 4), traffic=None, launches=int(n),
                     avg_launch_us=round(ms * 1e3 / max(n, 1), 2), event_bracket_us_subtracted=round(ev_us, 2),
                     measured_in=("timed region (single stream)" if not serial_steps else
                                  "serialized replay of %d steps after the timed region (one stream)" % serial_steps),
@@ -332,7 +345,7 @@ def main():
         # the HBM rate of the pool bytes it streams (bf16 shadow: Q * D * 2 per sweep)
         pool_bytes = Q // max(world if sharded else 1, 1) * args.feat * 2
         (roofline if dom == "head_sweep_kernel" else roofline["other"]["head_sweep_kernel"]).update(
-            avg_launch_us=round(hs[0] * 1e3 / hs[2], 1), mfma_frac=round(hs[1] / (hs[0] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            avg_launch_us=round(hs[0] * 1e3 / hs[2], 1), mfma_frac=round(hs[1] / (hs[0] * 1e-3) / 1e12 / head_peak, 4), mfma_peak=head_peak,
             pool_gb_per_s=round(pool_bytes * hs[2] / (hs[0] * 1e-3) / 1e9, 1))
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be collected from inside this
     # process, so the figure measured by rocprofv3 --pmc on this same command (profiles/) is attached
@@ -353,7 +366,7 @@ def main():
                        "%dM" % (args.identities >> 20) if args.identities >= (1 << 20) else str(args.identities), args.net)),
         "value": round(faces / dt, 2), "unit": "faces/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.head_dtype == "bf16" else "bf16 backbone + fp8 (e4m3) class matmul", "data": "synthetic",
         "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
                                "(2 x %d faces per step per GPU), SGD-nesterov, %dx%d synthetic images" %
                                (args.net, args.identities, Q, args.feat, args.loss, B, B, hw, hw),

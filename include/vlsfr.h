@@ -123,6 +123,13 @@ int vlsfr_pool_scatter(float* queue, int64_t Q, int32_t D, const float* g /*[n, 
  * master stays the source of truth (special columns, precise mode, checkpoint); the caller rebuilds the shadow
  * whenever it changes queue[0] by other means than vlsfr_pool_scatter (load_state_dict, copy_). */
 int vlsfr_pool_shadow_build(const float* queue0 /*[Q, D]*/, void* shadow_bf16, int64_t Q, int32_t D, void* stream);
+/* fp8 (e4m3, values x 64) shadow of queue[0] for the fp8 sweep, stored fragment-major in tiles of 128 slots (layout:
+ * csrc/head8.hip): vlsfr_pool_shadow8_bytes(Q) bytes.  _update rewrites the images of `n` slots (global ids in `cols`,
+ * device; slots outside [slot_lo, slot_lo + Q) are skipped) from the fp32 master after vlsfr_pool_scatter changed them. */
+size_t vlsfr_pool_shadow8_bytes(int64_t Q);
+int vlsfr_pool_shadow8_build(const float* queue0 /*[Q, 512]*/, void* shadow8, int64_t Q, int32_t D, void* stream);
+int vlsfr_pool_shadow8_update(const float* queue0, int64_t Q, int32_t D, const int32_t* cols /*[n] dev*/, int32_t n,
+                              int32_t slot_lo, void* shadow8, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 4. Fused DCP head (device): loss and dL/dp of one FFC pass in one sweep over queue[0].
@@ -156,6 +163,9 @@ typedef struct vlsfr_head_cfg {
                              F.normalize output (ffc.py:30,182), so |cos| <= |p| — to fix the softmax reference
                              exponent per row up front instead of tracking a running maximum.  The workspace size
                              depends on this field: query with the cfg the call will use. */
+  const void* pool_fp8;   /* NULL, or the fp8 (OCP e4m3) shadow of queue[0] (vlsfr_pool_shadow8_build): the sweep then runs
+                             both contractions on v_mfma_scale_f32_16x16x128_f8f6f4 (csrc/head8.hip; config C5's precision:
+                             cosines and dL/dp to ~1e-2, loss to ~1e-3).  Same conditions as pool_bf16, which it overrides. */
 } vlsfr_head_cfg;
 
 /* sizeof(vlsfr_head_cfg) as this library was compiled: bindings assert their mirror of the struct against it */
@@ -348,6 +358,18 @@ int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const floa
 int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, const float* const* params,
                                   float* const* grads, const void* wcache, void* ctx, void* scratch,
                                   void* const* stage_events, void* stream);
+/* The same pass with the weight-gradient kernels on `side_stream`: the input-gradient chain alternates MFMA-bound and
+ * HBM-bound kernels and nothing in it waits for a weight gradient, so those run beside it (ring of gradient buffers,
+ * event-ordered; results identical up to the order of the fp32 atomics).  ring: vlsfr_iresnet_overlap_ring_bytes(n)
+ * bytes of device memory; events: vlsfr_iresnet_overlap_events() events from vlsfr_event_create, owned by the caller and
+ * reusable across calls issued on the same pair of streams.  On return the main stream is ordered behind every
+ * side-stream kernel.  stage_events as in vlsfr_iresnet_backward_staged (may be NULL). */
+size_t vlsfr_iresnet_overlap_ring_bytes(const vlsfr_iresnet* n);
+int32_t vlsfr_iresnet_overlap_events(void);
+int vlsfr_iresnet_backward_overlap(const vlsfr_iresnet* n, const float* demb, const float* const* params,
+                                   float* const* grads, const void* wcache, void* ctx, void* scratch, void* ring,
+                                   size_t ring_bytes, void* const* stage_events, void* side_stream,
+                                   void* const* events, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7b. MobileFaceNet backbone executor: same contract as section 7 for reference

@@ -312,15 +312,15 @@ def test_shadow_sweep_matches_fp32_stream_and_tracks_the_pool(monkeypatch):
                     out.append((float(loss), p.grad.cpu().numpy()))
                 np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-5)
                 np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-3, atol=2e-4 * np.abs(out[1][1]).max())
-        assert fast.shadow.t is not None and slow.shadow.t is None
-        assert torch.equal(fast.shadow.t, fast.queue[0].to(torch.bfloat16))
+        assert fast.shadow.t.get('bf16') is not None and slow.shadow.t.get('bf16') is None
+        assert torch.equal(fast.shadow.t['bf16'], fast.queue[0].to(torch.bfloat16))
         assert torch.equal(fast.queue, slow.queue)
     monkeypatch.setenv("VLSFR_HEAD_SHADOW", "1")
     rng = np.random.default_rng(5)
     fast.queue.copy_(torch.from_numpy(common.unit_rows(rng, 2, Q, D)).cuda())
     p = torch.from_numpy(case["P"][0, 0]).cuda()
     fast.run_pass(p, torch.from_numpy(case["G"][0, 0]).cuda(), case["XL"][0], case["YL"][0], True)
-    assert torch.equal(fast.shadow.t, fast.queue[0].to(torch.bfloat16))
+    assert torch.equal(fast.shadow.t['bf16'], fast.queue[0].to(torch.bfloat16))
 
 
 def test_head_metric_size_properties():
@@ -347,7 +347,7 @@ def test_head_metric_size_properties():
         loss = head.run_pass(p, g, labels, labels, True)
         loss.backward()
         torch.cuda.synchronize()
-        sh = head.shadow.t
+        sh = head.shadow.t['bf16']
         assert sh is not None
         for a0 in range(0, Q, 1 << 20):          # rollback: pool untouched, shadow == bf16(pool)
             assert torch.equal(sh[a0:a0 + (1 << 20)], queue0[0, a0:a0 + (1 << 20)].to(torch.bfloat16))
@@ -413,8 +413,84 @@ def test_identity_sharded_head_world8_bf16_shadow(loss_type, margin, n_id):
                 np.testing.assert_allclose(float(l), float(loss.detach()), rtol=5e-5, atol=1e-5)
                 np.testing.assert_allclose(dP.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-3,
                                            atol=2e-4 * float(p.grad.abs().max()))
-    assert all(h.shadow.t is not None for h in shards)
+    assert all(h.shadow.t.get('bf16') is not None for h in shards)
     assert torch.equal(torch.cat([h.queue for h in shards], dim=1), full.queue)
-    assert torch.equal(torch.cat([h.shadow.t for h in shards], dim=0), full.shadow.t)
+    assert torch.equal(torch.cat([h.shadow.t['bf16'] for h in shards], dim=0), full.shadow.t['bf16'])
     for h in shards:
         assert h.lru.state_dict() == full.lru.state_dict() and h.qp.tolist() == full.qp.tolist()
+
+
+# ---- fp8 (OCP e4m3) sweep: csrc/head8.hip, the fp8 slice of config C5 (SURVEY 8d tolerances: cos >= 0.99, loss rtol 5e-2) ----
+def _decode_shadow8(buf, Q):
+    """The fragment-major fp8 shadow (csrc/head8.hip header) back to two [ceil(Q/128)*128, 512] byte matrices: the R part
+    (operand of the first product) and the T part (the transposed tile, operand of the second)."""
+    nt = (Q + 127) // 128
+    b = buf.view(nt, 131072)
+    R = b[:, :65536].reshape(nt, 8, 4, 2, 4, 16, 16)            # [tile][mb][ks][half][g][m][byte]
+    Rm = R.permute(0, 1, 5, 2, 4, 3, 6).reshape(nt * 128, 512)  # row 16 mb + m, feature 128 ks + 32 g + 16 half + byte
+    T = b[:, 65536:].reshape(nt, 32, 2, 4, 16, 4, 4)            # [tile][nb][half][g][n][byte >> 2][byte & 3]
+    Tm = T.permute(0, 2, 5, 3, 6, 1, 4).reshape(nt * 128, 512)  # row 16 (4 half + (byte >> 2)) + 4 g + (byte & 3), feature 16 nb + n
+    return Rm, Tm
+
+
+def _expected_fp8(queue0_dev, Q):
+    want = torch.zeros((Q + 127) // 128 * 128, 512, dtype=torch.uint8, device=queue0_dev.device)
+    want[:Q] = (queue0_dev * 64.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    return want
+
+
+def test_fp8_shadow_layout_and_updates():
+    """vlsfr_pool_shadow8_build writes e4m3(64 x) of every pool row into both fragment-major parts (ragged Q: the rows past
+    the pool are zeros); after committing passes the image equals a fresh build of the updated pool, byte for byte."""
+    Q, B = 3001, 40
+    case = common.head_case(77, Q, 512, B, 2, 9000)
+    head = make_head(case["queue0"], "Arc", 32.0, 0.5, False)
+    head.head_dtype = "fp8"
+    assert head.shadow.ptr(True, "fp8") is not None
+    Rm, Tm = _decode_shadow8(head.shadow.t["fp8"], Q)
+    want = _expected_fp8(head.queue[0], Q)
+    assert torch.equal(Rm, want) and torch.equal(Tm, want)
+    for t in range(2):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            p = torch.from_numpy(case["P"][t, s]).cuda().requires_grad_(True)
+            head.run_pass(p, torch.from_numpy(case["G"][t, s]).cuda(), pl, gl, trans).backward()
+    Rm, Tm = _decode_shadow8(head.shadow.t["fp8"], Q)
+    want2 = _expected_fp8(head.queue[0], Q)
+    assert not torch.equal(want2, want)                       # the commits wrote rows
+    assert torch.equal(Rm, want2) and torch.equal(Tm, want2)
+    assert head.shadow.t.get("bf16") is None                  # the fp8 head never builds the bf16 mirror
+
+
+@pytest.mark.parametrize("loss_type,margin", [("Arc", 0.5), ("AM", 0.4), ("SV", 0.35)])
+@pytest.mark.parametrize("Q,B,n_id", [(3001, 40, 9000), (70000, 256, 50000), (66000, 200, 90000)])
+def test_head_fp8_vs_oracle(loss_type, margin, Q, B, n_id):
+    """The e4m3 sweep against the float64 oracle: ragged Q (not a multiple of the 128-column tile), B below / above one
+    128-row block and not a multiple of 16, outlier rows (n_id > Q: hard-negative top-k).  Bookkeeping and pool rows are
+    exact (the fp32 master is what is written); loss within 5e-3 (SURVEY: 5e-2), every dL/dp row within cos 0.99 of the
+    oracle's and the whole dL/dp within 8 % rel-L2 — the fp8 rounding of pool, probe and numerators."""
+    T, D = 3, 512
+    case = common.head_case(3000 + Q + B, Q, D, B, T, n_id)
+    head = make_head(case["queue0"], loss_type, 32.0, margin, False)
+    head.head_dtype = "fp8"
+    queue = torch.from_numpy(case["queue0"]).double()
+    lru, qp = LRURef(Q), [0] * Q
+    for t in range(T):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            want_loss, want_dp = oracle_pass(queue, lru, qp, case["P"][t, s], case["G"][t, s], pl, gl, trans,
+                                             loss_type, 32.0, margin, head.hard_neg)
+            p = torch.from_numpy(case["P"][t, s]).cuda().requires_grad_(True)
+            loss = head.run_pass(p, torch.from_numpy(case["G"][t, s]).cuda(), pl, gl, trans)
+            loss.backward()
+            np.testing.assert_allclose(float(loss), want_loss, rtol=5e-3)
+            got = p.grad.double().cpu().numpy()
+            num = (got * want_dp).sum(1)
+            den = np.linalg.norm(got, axis=1) * np.linalg.norm(want_dp, axis=1)
+            live = den > 1e-12 * max(den.max(), 1e-30)
+            assert (num[live] / den[live]).min() > 0.99
+            assert np.linalg.norm(got - want_dp) <= 0.08 * np.linalg.norm(want_dp)
+    assert head.shadow.t.get("fp8") is not None
+    assert head.lru.state_dict() == lru.state_dict()
+    assert head.qp.tolist() == qp
+    np.testing.assert_array_equal(head.queue.cpu().numpy(), queue.float().numpy())

@@ -1000,7 +1000,7 @@ int round_dp(int D) {
 int g_head_variant = -1;   // "head_variant": bf16-shadow sweep geometry (head_sweep16.h); -1 = by batch size
 
 struct Plan {
-  bool fast;   // bf16-shadow sweep (head16.hip)
+  bool fast;   // shadow sweep: bf16 (head16.hip, variants 0 / 1) or fp8 (head8.hip, variant 2)
   int variant;
   int DP, Bp, n_chunks, chunk_cols, n_rowblk;
   size_t off_m, off_l, off_o, off_tv, off_ti, off_cos1, off_cos2, off_thr, off_rowloss, total;
@@ -1016,22 +1016,25 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   pl->DP = round_dp(c->D);
   // The bf16-shadow sweep: D = 512, plain bf16 operands, and a logit range its fixed reference exponent covers
   // (head16.hip: scale <= 64; larger scales keep the online-maximum kernel)
-  pl->fast = c->pool_bf16 != nullptr && !c->precise && c->D == SW16_D && c->scale > 0.f && c->scale * LOG2E <= 93.f;
+  const bool range_ok = !c->precise && c->D == SW16_D && c->scale > 0.f && c->scale * LOG2E <= 93.f;
+  const bool fp8 = c->pool_fp8 != nullptr && range_ok;       // fp8 sweep (head8.hip) when its shadow is given
+  pl->fast = (c->pool_bf16 != nullptr && range_ok) || fp8;
   pl->variant = 0;
   if (pl->fast) {
-    pl->variant = g_head_variant >= 0 ? g_head_variant : (c->B > 64 ? 1 : 0);
+    pl->variant = fp8 ? 2 : g_head_variant >= 0 ? g_head_variant : (c->B > 64 ? 1 : 0);
     const int rows_wg = sweep16_rows_per_wg(pl->variant);
+    const int tq = fp8 ? SW8_TQ : SW16_TQ, max_tiles = fp8 ? SW8_MAX_TILES : SW16_MAX_TILES;
     pl->n_rowblk = (c->B + rows_wg - 1) / rows_wg;
     pl->Bp = pl->n_rowblk * rows_wg;
-    const int64_t tiles = (c->Q + SW16_TQ - 1) / SW16_TQ;
+    const int64_t tiles = (c->Q + tq - 1) / tq;
     // one workgroup per CU (the accumulators and the P fragments own the register file): whole rounds of 256
     int nch = c->n_chunks > 0 ? c->n_chunks : (256 + pl->n_rowblk - 1) / pl->n_rowblk;
     if (nch < 8) nch = 8;
     nch = (nch + 7) & ~7;
-    while ((tiles + nch - 1) / nch > SW16_MAX_TILES) nch *= 2;
+    while ((tiles + nch - 1) / nch > max_tiles) nch *= 2;
     if (nch > tiles) nch = (int)((tiles + 7) & ~(int64_t)7);
     const int64_t per = (tiles + nch - 1) / nch;
-    pl->chunk_cols = (int)per * SW16_TQ;
+    pl->chunk_cols = (int)per * tq;
     pl->n_chunks = (int)((c->Q + pl->chunk_cols - 1) / pl->chunk_cols);
     pl->n_chunks = (pl->n_chunks + 7) & ~7;
   } else {
@@ -1072,6 +1075,89 @@ int make_plan(const vlsfr_head_cfg* c, Plan* pl) {
   pl->off_rowloss = take((size_t)c->B * 2 * 4);
   pl->total = off;
   return VLSFR_OK;
+}
+
+// fp8 sweep only: the hard-negative candidates of an outlier row were ranked by e4m3 cosines (~3e-3 off), which swaps
+// members among near-ties of the top-k (ffc.py:86-90 takes it from exact cosines).  This pass keeps the RS_M best
+// candidates of the row by their approximate value, recomputes their cosines in fp32 from the master rows, and leaves
+// exactly those — with exact values — in the row's candidate lists (chunk 0's 4 x KTOP entries; every other entry is
+// emptied), so head_finish / head_shard_finish select and score the top-k as the fp32 kernels would.
+constexpr int RS_M = 32;
+__global__ __launch_bounds__(256) void topk_rescore_kernel(const float* p, const float* w0, const int32_t* pool_label, float* topk_val,
+                                                           int32_t* topk_idx, int n_chunks, int Bp, int D) {
+  const int i = blockIdx.x;
+  if (pool_label[i] >= 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int sel_i[RS_M];
+  __shared__ float ex[RS_M];
+  __shared__ float wv[4];
+  __shared__ long long wk[4];
+  const size_t ncand = (size_t)n_chunks * 4 * KTOP;
+  float last_v = 3.0e38f;
+  long long last_k = -1;
+  int nsel = 0;
+  for (int k = 0; k < RS_M; ++k) {
+    float bv = NEG_BIG;
+    long long bk = 0x7fffffffffffffffLL;
+    for (size_t c = tid; c < ncand; c += 256) {
+      const size_t chunk = c / (4 * KTOP), rest = c % (4 * KTOP);
+      const size_t off = ((chunk * Bp + i) * 4) * KTOP + rest;
+      const float cv = topk_val[off];
+      const long long key = topk_idx[off];
+      if (cv <= NEG_BIG || key < 0) continue;
+      if (!((cv < last_v) || (cv == last_v && key > last_k))) continue;
+      if (cv > bv || (cv == bv && key < bk)) {
+        bv = cv;
+        bk = key;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const long long ok = __shfl_xor(bk, o, 64);
+      if (ov > bv || (ov == bv && ok < bk)) {
+        bv = ov;
+        bk = ok;
+      }
+    }
+    if (lane == 0) {
+      wv[wave] = bv;
+      wk[wave] = bk;
+    }
+    __syncthreads();
+    bv = wv[0];
+    bk = wk[0];
+    for (int w = 1; w < 4; ++w)
+      if (wv[w] > bv || (wv[w] == bv && wk[w] < bk)) {
+        bv = wv[w];
+        bk = wk[w];
+      }
+    __syncthreads();
+    if (bv <= NEG_BIG) break;
+    last_v = bv;
+    last_k = bk;
+    if (tid == 0) sel_i[k] = (int)bk;
+    ++nsel;
+  }
+  __syncthreads();
+  for (int m = wave; m < nsel; m += 4) {
+    const float* vec = w0 + (size_t)sel_i[m] * D;
+    float acc = 0.f;
+    for (int d = lane; d < D; d += 64) acc += p[(size_t)i * D + d] * vec[d];
+    acc = wave_sum(acc);
+    if (lane == 0) ex[m] = acc;
+  }
+  for (size_t c = tid; c < ncand; c += 256) {
+    const size_t chunk = c / (4 * KTOP), rest = c % (4 * KTOP);
+    const size_t off = ((chunk * Bp + i) * 4) * KTOP + rest;
+    topk_val[off] = NEG_BIG;
+    topk_idx[off] = -1;
+  }
+  __syncthreads();
+  if (tid < nsel) {
+    const size_t off = ((size_t)i * 4) * KTOP + tid;   // chunk 0
+    topk_val[off] = ex[tid];
+    topk_idx[off] = sel_i[tid];
+  }
 }
 
 template <int DP, bool PRECISE>
@@ -1124,6 +1210,7 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
       Sweep16Args f;
       f.p = a.p;
       f.w16 = (const uint16_t*)cfg->pool_bf16;
+      f.w8 = (const uint8_t*)cfg->pool_fp8;
       f.Q = a.Q;
       f.B = a.B;
       f.chunk_cols = a.chunk_cols;
@@ -1147,6 +1234,12 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
       rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st) : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
     }
     if (rc != VLSFR_OK) return rc;
+  }
+  if (pl.variant == 2 && pl.fast && want_topk) {
+    static_assert(RS_M <= 4 * KTOP, "the rescored candidates live in one chunk's lists");
+    hipLaunchKernelGGL(topk_rescore_kernel, dim3(a.B), dim3(256), 0, st, a.p, a.w0, a.pool_label, a.topk_val, a.topk_idx, pl.n_chunks,
+                       pl.Bp, a.D);
+    VLSFR_HIP_CHECK_LAUNCH("topk_rescore launch");
   }
   return VLSFR_OK;
 }

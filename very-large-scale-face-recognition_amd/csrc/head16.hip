@@ -371,7 +371,8 @@ size_t sweep16_lds_bytes(int chunk_cols) { return (size_t)NS * TILE_B + (size_t)
 int sweep16_rows_per_wg(int variant) { return variant == 0 ? 64 : 128; }
 
 int launch_sweep16(const Sweep16Args& a, int variant, bool topk, bool sv, hipStream_t st) {
-  if (variant < 0 || variant > 1) return fail(VLSFR_EINVAL, "head_sweep16: variant must be 0 or 1");
+  if (variant == 2) return launch_sweep8(a, topk, sv, st);
+  if (variant < 0 || variant > 1) return fail(VLSFR_EINVAL, "head_sweep16: variant must be 0, 1 or 2");
   if (a.chunk_cols % TQ != 0 || a.chunk_cols / TQ > SW16_MAX_TILES || a.n_chunks % 8 != 0 ||
       a.Bp != a.n_rowblk * sweep16_rows_per_wg(variant))
     return fail(VLSFR_EINVAL, "head_sweep16: inconsistent plan (chunk_cols %d, n_chunks %d, Bp %d)", a.chunk_cols, a.n_chunks, a.Bp);

@@ -472,4 +472,170 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   return signal(4);
 }
 
+// ---- backward pass with the weight gradients on a second stream -------------------------------------------------
+// The input-gradient chain (BatchNorm backward -> dgrad -> BatchNorm backward -> ...) is a strict dependency chain that
+// alternates MFMA-bound and HBM-bound kernels; the weight gradient of a layer depends only on that layer's dY and its
+// saved input, and nothing in the chain depends on it.  Here every gradient tensor of the chain takes the next slot of
+// a ring of OVERLAP_NR buffers instead of rotating through three, and the weight-gradient kernels go to `side_stream`:
+// they may lag the chain by up to a block and run under its BatchNorm kernels.  Ordering: event ev_main[s] (recorded on
+// the main stream after the kernel that writes slot s) gates the side-stream reader; event ev_side[s] (recorded after the
+// reader) gates the next main-stream writer of slot s.  events = [ev_main[0..NR) | ev_side[0..NR) | join].
+namespace {
+constexpr int OVERLAP_NR = 10;   // a block writes 5 (6 with a shortcut conv) tensors and its input gradient is live to the end
+struct Ring {
+  char* base;
+  size_t stride;
+  hipStream_t main, side;
+  hipEvent_t* ev_main;
+  hipEvent_t* ev_side;
+  bool pending[OVERLAP_NR];
+  int next;
+  hipError_t err;
+  char* slot(int s) const { return base + (size_t)s * stride; }
+  int acquire() {   // next slot, safe to write from the main stream
+    const int s = next;
+    next = (next + 1) % OVERLAP_NR;
+    if (pending[s]) {
+      hipError_t e = hipStreamWaitEvent(main, ev_side[s], 0);
+      if (e != hipSuccess) err = e;
+      pending[s] = false;
+    }
+    return s;
+  }
+  void produced(int s) {   // the kernel writing slot s has been enqueued on the main stream
+    hipError_t e = hipEventRecord(ev_main[s], main);
+    if (e != hipSuccess) err = e;
+  }
+  void side_begin(int s) {
+    hipError_t e = hipStreamWaitEvent(side, ev_main[s], 0);
+    if (e != hipSuccess) err = e;
+  }
+  void side_end(int s) {
+    hipError_t e = hipEventRecord(ev_side[s], side);
+    if (e != hipSuccess) err = e;
+    pending[s] = true;
+  }
+};
+}  // namespace
+
+size_t vlsfr_iresnet_overlap_ring_bytes(const vlsfr_iresnet* n) { return n ? (size_t)OVERLAP_NR * align_up(n->max_act) : 0; }
+int32_t vlsfr_iresnet_overlap_events(void) { return 2 * OVERLAP_NR + 1; }
+
+int vlsfr_iresnet_backward_overlap(const vlsfr_iresnet* n, const float* demb, const float* const* params,
+                                   float* const* grads, const void* wcache, void* ctx_v, void* scratch, void* ring_v,
+                                   size_t ring_bytes, void* const* stage_events, void* side_stream, void* const* events,
+                                   void* st) {
+  if (!n || !demb || !params || !grads || !wcache || !ctx_v || !scratch || !ring_v || !side_stream || !events)
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_backward_overlap: null argument");
+  if (ring_bytes < vlsfr_iresnet_overlap_ring_bytes(n))
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_backward_overlap: ring of %zu bytes, %zu needed", ring_bytes,
+                vlsfr_iresnet_overlap_ring_bytes(n));
+  for (int i = 0; i < 2 * OVERLAP_NR + 1; ++i)
+    if (!events[i]) return fail(VLSFR_EINVAL, "vlsfr_iresnet_backward_overlap: null event %d", i);
+  hipStream_t sm = (hipStream_t)st, ss = (hipStream_t)side_stream;
+  Ring R;
+  R.base = (char*)ring_v;
+  R.stride = align_up(n->max_act);
+  R.main = sm;
+  R.side = ss;
+  R.ev_main = (hipEvent_t*)events;
+  R.ev_side = (hipEvent_t*)events + OVERLAP_NR;
+  for (bool& p : R.pending) p = false;
+  R.next = 0;
+  R.err = hipSuccess;
+  hipEvent_t ev_join = (hipEvent_t)events[2 * OVERLAP_NR];
+  auto join = [&]() -> int {   // the main stream continues once every weight gradient enqueued so far is done
+    hipError_t e = hipEventRecord(ev_join, ss);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sm, ev_join, 0);
+    return e == hipSuccess ? VLSFR_OK : fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: join: %s", hipGetErrorString(e));
+  };
+  auto signal = [&](int k) -> int {
+    if (!stage_events || !stage_events[k]) return VLSFR_OK;
+    int rc = join();
+    if (rc) return rc;
+    hipError_t ee = hipEventRecord((hipEvent_t)stage_events[k], sm);
+    return ee == hipSuccess ? VLSFR_OK : fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: hipEventRecord: %s", hipGetErrorString(ee));
+  };
+  // the weight gradient of `c` from dY in ring slot s and the saved input x, on the side stream
+  auto wgrad_side = [&](const Conv& c, int s, const void* x) -> int {
+    R.side_begin(s);
+    int rc = vlsfr_conv2d_wgrad(&c.d, R.slot(s), x, grads[c.p_w], 0, ss);
+    R.side_end(s);
+    return rc;
+  };
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  Scratch sc = carve(n, scratch);
+  const int B = n->B, S = n->HW0;
+  const Block& last = n->blocks.back();
+  const int HWl = last.Ho * last.Wo;
+  hipError_t e0 = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, sm);
+  if (e0 != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: memset: %s", hipGetErrorString(e0));
+  {   // the side stream starts behind everything the main stream has done so far (forward pass, head, zeroed gradients)
+    hipError_t e = hipEventRecord(ev_join, sm);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ss, ev_join, 0);
+    if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: fork: %s", hipGetErrorString(e));
+  }
+  RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
+                      (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd),
+                      params[n->p_feat_w], sc.dz, sc.dfc, grads[n->p_feat_b], grads[n->p_fc_b], nullptr, B, n->D, sm));
+  RUN(vlsfr_conv2d_wgrad(&n->fc.d, sc.dfc, ctx + n->off_flat, grads[n->fc.p_w], 0, sm));
+  const int s_flat = R.acquire();
+  RUN(vlsfr_conv2d_dgrad(&n->fc.d, sc.dfc, wc + n->fc.off_wT, R.slot(s_flat), sm));
+  int s_cur = R.acquire();
+  RUN(bn_backward(n->bn_last, R.slot(s_flat), ctx + last.out, R.slot(s_cur), (int64_t)B * HWl, HWl, nullptr, 1, params, grads,
+                  ctx, sm));
+  RUN(signal(0));
+  int stage = 4, left = n->layers[3];
+  for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
+    const Block& b = n->blocks[k];
+    const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
+    const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
+    const char* dout = R.slot(s_cur);
+    const int s_c2 = R.acquire();
+    RUN(bn_backward(b.bn3, dout, ctx + b.c2, R.slot(s_c2), Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, sm));
+    R.produced(s_c2);
+    RUN(wgrad_side(b.conv2, s_c2, ctx + b.a2));
+    const int s_a2 = R.acquire();
+    RUN(vlsfr_conv2d_dgrad(&b.conv2.d, R.slot(s_c2), wc + b.conv2.off_wT, R.slot(s_a2), sm));
+    const int s_c1 = R.acquire();
+    RUN(bn_backward(b.bn2, R.slot(s_a2), ctx + b.c1, R.slot(s_c1), Min, b.H * b.W, nullptr, 0, params, grads, ctx, sm));
+    R.produced(s_c1);
+    RUN(wgrad_side(b.conv1, s_c1, ctx + b.a1));
+    const int s_a1 = R.acquire();
+    RUN(vlsfr_conv2d_dgrad(&b.conv1.d, R.slot(s_c1), wc + b.conv1.off_wT, R.slot(s_a1), sm));
+    const char* add = dout;
+    if (b.has_ds) {
+      const int s_cs = R.acquire();
+      RUN(bn_backward(b.bnd, dout, ctx + b.cs, R.slot(s_cs), Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, sm));
+      R.produced(s_cs);
+      RUN(wgrad_side(b.convd, s_cs, x_in));
+      RUN(vlsfr_conv2d_dgrad(&b.convd.d, R.slot(s_cs), wc + b.convd.off_wT, sc.idn, sm));
+      add = sc.idn;
+    }
+    const int s_x = R.acquire();
+    RUN(bn_backward(b.bn1, R.slot(s_a1), x_in, R.slot(s_x), Min, b.H * b.W, add, 0, params, grads, ctx, sm));
+    s_cur = s_x;
+    if (R.err != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: event: %s", hipGetErrorString(R.err));
+    if (--left == 0 && stage > 1) {
+      RUN(signal(5 - stage));
+      --stage;
+      left = n->layers[stage - 1];
+    }
+  }
+  const int s_c0 = R.acquire();
+  RUN(bn_backward(n->stem_bn, R.slot(s_cur), ctx + n->off_c0, R.slot(s_c0), (int64_t)B * S * S, S * S, nullptr, 0, params, grads,
+                  ctx, sm));
+  hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, sm);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_conv2d_wgrad(&n->stem.d, R.slot(s_c0), ctx + n->off_cols, sc.stem_dw, 0, sm));
+  RUN(vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, sm));
+  RUN(join());
+  if (stage_events && stage_events[4]) {
+    hipError_t ee = hipEventRecord((hipEvent_t)stage_events[4], sm);
+    if (ee != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: hipEventRecord: %s", hipGetErrorString(ee));
+  }
+  return VLSFR_OK;
+}
+
 }  // extern "C"

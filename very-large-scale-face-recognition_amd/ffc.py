@@ -123,6 +123,8 @@ class FFC(Module):
         # the reference reads these attributes on every add_margin call (ffc.py:60-138): follow later changes
         head.scale, head.margin, head.loss_type, head.precise = float(self.scale), float(self.margin), self.loss_type, bool(self.precise_head)
         head.hard_neg = int(self.hard_neg)
+        if self.__dict__.get('head_dtype'):          # 'bf16' | 'fp8' (e4m3 sweep, config C5's precision); default: VLSFR_HEAD_DTYPE or bf16
+            head.head_dtype = self.__dict__['head_dtype']
         return head
 
     @torch.no_grad()

@@ -22,7 +22,8 @@ class HeadCfg(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("D", ctypes.c_int32), ("Q", ctypes.c_int64),
                 ("loss_type", ctypes.c_int32), ("scale", ctypes.c_float), ("margin", ctypes.c_float),
                 ("hard_neg", ctypes.c_int32), ("precise", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
-                ("slot_lo", ctypes.c_int32), ("n_rows_total", ctypes.c_int32), ("pool_bf16", ctypes.c_void_p)]
+                ("slot_lo", ctypes.c_int32), ("n_rows_total", ctypes.c_int32), ("pool_bf16", ctypes.c_void_p),
+                ("pool_fp8", ctypes.c_void_p)]
 
 
 def _check_abi(L):
@@ -35,28 +36,57 @@ def _check_abi(L):
 
 
 class PoolShadow(object):
-    """bf16 mirror of queue[0] that the head sweep streams (include/vlsfr.h section 3): built on first use,
-    kept current by vlsfr_pool_scatter, rebuilt when queue was modified through torch (its version counter moved:
-    load_state_dict, copy_).  Only for D = 512 and plain bf16 operands — the cases csrc/head16.hip covers."""
+    """Reduced-precision mirror of queue[0] that the head sweep streams (include/vlsfr.h section 3): built on first use,
+    kept current after vlsfr_pool_scatter, rebuilt when queue was modified through torch (its version counter moved:
+    load_state_dict, copy_).  Only for D = 512 and plain operands — the cases csrc/head16.hip / head8.hip cover.
+    dtype "bf16": [Q, 512] bf16, updated by vlsfr_pool_scatter itself; "fp8": the fragment-major e4m3 image of
+    csrc/head8.hip (config C5's precision), updated by vlsfr_pool_shadow8_update after the scatter."""
 
     def __init__(self, queue):
         self.queue = queue
-        self.t = None
-        self.version = None
+        self.t = {}            # dtype -> tensor
+        self.version = {}
 
-    def ptr(self, enabled):
+    def _usable(self, enabled):
+        return enabled and self.queue.shape[2] == 512 and os.environ.get("VLSFR_HEAD_SHADOW", "1") != "0"
+
+    def ptr(self, enabled, dtype="bf16"):
+        """Device pointer of the current mirror in `dtype` (None when the sweep must read the fp32 pool)."""
         q = self.queue
-        if not enabled or q.shape[2] != 512 or os.environ.get("VLSFR_HEAD_SHADOW", "1") == "0":
+        if not self._usable(enabled):
             return None
-        if self.t is None:
-            self.t = torch.empty(q.shape[1], q.shape[2], dtype=torch.bfloat16, device=q.device)
-        if self.version != q._version:
-            fn = _lib.lib().vlsfr_pool_shadow_build
+        L = _lib.lib()
+        if dtype not in self.t:
+            if dtype == "fp8":
+                L.vlsfr_pool_shadow8_bytes.restype = ctypes.c_size_t
+                self.t[dtype] = torch.empty(int(L.vlsfr_pool_shadow8_bytes(ctypes.c_int64(q.shape[1]))), dtype=torch.uint8, device=q.device)
+            else:
+                self.t[dtype] = torch.empty(q.shape[1], q.shape[2], dtype=torch.bfloat16, device=q.device)
+        t = self.t[dtype]
+        if self.version.get(dtype) != q._version:
+            fn = L.vlsfr_pool_shadow8_build if dtype == "fp8" else L.vlsfr_pool_shadow_build
             fn.restype = ctypes.c_int
-            _lib.check(fn(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(self.t.data_ptr()), ctypes.c_int64(q.shape[1]),
+            _lib.check(fn(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(t.data_ptr()), ctypes.c_int64(q.shape[1]),
                           ctypes.c_int32(q.shape[2]), _stream_ptr()), "vlsfr_pool_shadow_build")
-            self.version = q._version
-        return self.t.data_ptr()
+            self.version[dtype] = q._version
+        return t.data_ptr()
+
+    def scatter_target(self):
+        """The bf16 mirror's pointer for vlsfr_pool_scatter (which writes the fp32 row and its bf16 image in one launch)."""
+        t = self.t.get("bf16")
+        return self.ptr(True) if t is not None else None
+
+    def after_scatter(self, cols_ptr, n, slot_lo=0):
+        """Refresh the fp8 images of the slots vlsfr_pool_scatter just wrote (cols: device int32, global slot ids)."""
+        t = self.t.get("fp8")
+        if t is None or self.version.get("fp8") != self.queue._version:
+            return                                   # not built yet, or stale anyway: the next ptr() rebuilds it
+        q = self.queue
+        fn = _lib.lib().vlsfr_pool_shadow8_update
+        fn.restype = ctypes.c_int
+        _lib.check(fn(ctypes.c_void_p(q.data_ptr()), ctypes.c_int64(q.shape[1]), ctypes.c_int32(q.shape[2]), cols_ptr,
+                      ctypes.c_int32(n), ctypes.c_int32(slot_lo), ctypes.c_void_p(t.data_ptr()), _stream_ptr()),
+                   "vlsfr_pool_shadow8_update")
 
 
 def _stream_ptr():
@@ -121,6 +151,7 @@ class DcpHead(object):
         self.Q, self.D = int(queue.shape[1]), int(queue.shape[2])
         self.scale, self.margin, self.loss_type = float(scale), float(margin), loss_type
         self.precise, self.n_chunks = bool(precise), int(n_chunks or os.environ.get('VLSFR_HEAD_CHUNKS', 0))
+        self.head_dtype = os.environ.get('VLSFR_HEAD_DTYPE', 'bf16')   # "fp8": the e4m3 sweep (config C5's precision)
         self.hard_neg = min(max(int(self.Q * 0.0002), 3), 10)          # ffc.py:48
         self.lru = LRU(self.Q)                                        # ffc.py:40
         self.qp = np.zeros(self.Q, dtype=np.uint8)                    # ffc.py:41-43
@@ -129,11 +160,13 @@ class DcpHead(object):
 
     # -------------------------------------------------------------------------------------------
     def _cfg(self, B, B_total=0):
+        fp8 = self.head_dtype == "fp8"
         return HeadCfg(B, self.D, self.Q, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), self.n_chunks, 0, B_total, self.shadow.ptr(not self.precise))
+                       int(self.precise), self.n_chunks, 0, B_total, None if fp8 else self.shadow.ptr(not self.precise),
+                       self.shadow.ptr(not self.precise, "fp8") if fp8 else None)
 
     def _workspace(self, cfg, device):
-        key = (cfg.B, cfg.n_rows_total, str(device), cfg.pool_bf16, cfg.precise, cfg.loss_type, cfg.scale)
+        key = (cfg.B, cfg.n_rows_total, str(device), cfg.pool_bf16, cfg.pool_fp8, cfg.precise, cfg.loss_type, cfg.scale)
         if self._ws_key != key:
             self.L.vlsfr_head_workspace_bytes.restype = ctypes.c_size_t
             self.L.vlsfr_head_workspace_bytes.argtypes = [ctypes.POINTER(HeadCfg)]
@@ -210,8 +243,9 @@ class DcpHead(object):
             sc.restype = ctypes.c_int
             rc = sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Q), ctypes.c_int32(self.D),
                     ctypes.c_void_p(gd.data_ptr()), at(10), at(11), ctypes.c_int32(n), ctypes.c_int32(0),
-                    ctypes.c_void_p(self.shadow.ptr(True) if self.shadow.t is not None else None), _stream_ptr())   # ffc.py:182
+                    ctypes.c_void_p(self.shadow.scatter_target()), _stream_ptr())   # ffc.py:182
             _lib.check(rc, "vlsfr_pool_scatter")
+            self.shadow.after_scatter(at(11), n)
         self._keep = (tab_d, pd, gd)     # keep operands alive until the next pass is enqueued
         return _HeadFn.apply(p, loss.reshape(()), dP)
 
@@ -238,6 +272,7 @@ class ShardedDcpHead(object):
         assert self.Qs * world == self.Q
         self.slot_lo = rank * self.Qs
         self.scale, self.margin, self.loss_type, self.precise = float(scale), float(margin), loss_type, bool(precise)
+        self.head_dtype = os.environ.get('VLSFR_HEAD_DTYPE', 'bf16')
         self.hard_neg = min(max(int(self.Q * 0.0002), 3), 10)
         self.lru = lru if lru is not None else LRU(self.Q)
         self.qp = qp if qp is not None else np.zeros(self.Q, dtype=np.uint8)
@@ -246,8 +281,10 @@ class ShardedDcpHead(object):
         self._ws, self._ws_key = None, None
 
     def _cfg(self, B):
+        fp8 = self.head_dtype == "fp8"
         return HeadCfg(B, self.D, self.Qs, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), 0, self.slot_lo, 0, self.shadow.ptr(not self.precise))
+                       int(self.precise), 0, self.slot_lo, 0, None if fp8 else self.shadow.ptr(not self.precise),
+                       self.shadow.ptr(not self.precise, "fp8") if fp8 else None)
 
     def begin(self, p_all, g_all, probe_label, gallery_label, transactional):
         """Bookkeeping of one pass (identical on every rank) and, for SV, this rank's view of the hard-example
@@ -257,7 +294,7 @@ class ShardedDcpHead(object):
         dev = p_all.device
         tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
         cfg = self._cfg(B)
-        key = (B, cfg.pool_bf16, cfg.precise, cfg.loss_type, cfg.scale)
+        key = (B, cfg.pool_bf16, cfg.pool_fp8, cfg.precise, cfg.loss_type, cfg.scale)
         if self._ws_key != key:
             fn = self.L.vlsfr_head_workspace_bytes
             fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.POINTER(HeadCfg)]
@@ -381,7 +418,8 @@ class ShardedDcpHead(object):
             _lib.check(sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Qs), ctypes.c_int32(D),
                           ctypes.c_void_p(st["gd"].data_ptr()), at(10), at(11), ctypes.c_int32(n),
                           ctypes.c_int32(self.slot_lo),
-                          ctypes.c_void_p(self.shadow.ptr(True) if self.shadow.t is not None else None), _stream_ptr()),
+                          ctypes.c_void_p(self.shadow.scatter_target()), _stream_ptr()),
                        "vlsfr_pool_scatter")
+            self.shadow.after_scatter(at(11), n, self.slot_lo)
         self._keep = st
         return row_loss.sum(), dP

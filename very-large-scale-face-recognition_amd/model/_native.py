@@ -68,6 +68,9 @@ class NativeBackbone(nn.Module):
     _cprefix = None
     feat_dim = None
     image_size = 112
+    overlap_wgrad = False      # True: executors that export <prefix>_backward_overlap run the weight gradients on a side stream
+                               # (measured at ir100 / batch 256: 94.0 vs 91.6 ms per step — a third and fourth MFMA-bound kernel
+                               # beside the two backward chains cost more in shared LDS / L2 than the BatchNorm gaps they fill)
 
     def _init_native(self):
         self._handles = {}
@@ -229,6 +232,26 @@ class NativeBackbone(nn.Module):
     def bucket_of(self, name):
         return 0
 
+    def _overlap_state(self, slot, h, device):
+        """Ring buffer, events and weight-gradient stream of backward pass `slot` (persistent: the ring is never handed
+        back to the allocator, so kernels of the side stream cannot outlive it)."""
+        st = self.__dict__.setdefault("_overlap", {})
+        L = _lib.lib()
+        fn = getattr(L, self._cprefix + "_overlap_ring_bytes")
+        fn.restype = ctypes.c_size_t
+        need = int(fn(h))
+        ov = st.get(slot)
+        if ov is None or ov["ring"].numel() < need or ov["ring"].device != device:
+            n_ev = int(getattr(L, self._cprefix + "_overlap_events")())
+            arr = (ctypes.c_void_p * n_ev)()
+            for k in range(n_ev):
+                e = ctypes.c_void_p()
+                _lib.check(L.vlsfr_event_create(ctypes.byref(e)), "vlsfr_event_create")
+                arr[k] = e.value
+            ov = dict(ring=torch.empty(need, dtype=torch.uint8, device=device), events=arr, stream=torch.cuda.Stream(device=device))
+            st[slot] = ov
+        return ov
+
     def stage_events(self, slot):
         """Events of backward pass `slot` (0 / 1: the two passes of an FFC step), one per bucket, created on first use;
         the pass records event k on ITS stream when bucket k's gradients are enqueued."""
@@ -254,6 +277,18 @@ class NativeBackbone(nn.Module):
         params, _ = self._tables()
         grads = self._ensure_grads()
         signal = self.__dict__.get("signal_stages", False)      # set by parallel.py: somebody waits on the events
+        overlap = getattr(L, self._cprefix + "_backward_overlap", None) if self.overlap_wgrad else None
+        if overlap is not None:
+            # weight gradients on their own stream beside the input-gradient chain of this pass (ring of gradient buffers)
+            ov = self._overlap_state(slot, h, demb.device)
+            overlap.restype = ctypes.c_int
+            _lib.check(overlap(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
+                               ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                               ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(ov["ring"].data_ptr()),
+                               ctypes.c_size_t(ov["ring"].numel()), self.stage_events(slot) if signal else None,
+                               ctypes.c_void_p(ov["stream"].cuda_stream), ov["events"], _stream()),
+                       self._cprefix + "_backward_overlap")
+            return
         staged = getattr(L, self._cprefix + "_backward_staged", None) if signal and self.N_BUCKETS > 1 else None
         if staged is not None:
             staged.restype = ctypes.c_int

@@ -235,6 +235,8 @@ class ShardedFFC(DataParallelFFC):
         model._head = None
         self.head = ShardedDcpHead(shard, self.rank, self.world, Q, model.scale, model.margin, model.loss_type,
                                    precise=model.precise_head, lru=state.lru, qp=state.qp)
+        if model.__dict__.get('head_dtype'):
+            self.head.head_dtype = model.__dict__['head_dtype']
 
     def gather_pool(self):
         """The whole pool [2, Q, D] on every rank (a collective; reference checkpoint format, main.py:85)."""
