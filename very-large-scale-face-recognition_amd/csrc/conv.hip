@@ -1524,6 +1524,11 @@ int vlsfr_set_option(const char* name, int32_t value) {
     g_wgrad_target = value > 0 ? value : 512;
     return VLSFR_OK;
   }
+  if (name && !strcmp(name, "bn_xcd")) {
+    extern int g_bn_xcd;
+    g_bn_xcd = value != 0;
+    return VLSFR_OK;
+  }
   if (name && !strcmp(name, "bn_block_kb")) {
     extern int g_bn_block_bytes;
     g_bn_block_bytes = value > 0 ? value * 1024 : 65536;

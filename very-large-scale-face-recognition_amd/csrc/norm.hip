@@ -150,6 +150,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, 
 // scale = gamma*invstd / shift = beta - mean*scale itself (a few L2-resident loads per thread), so
 // there is no separate finalize launch; block 0 also records mean / invstd and updates the running
 // statistics.  Optionally accumulates the statistics of y for the next BatchNorm.
+// Row range of a block.  Workgroups go to the 8 XCDs round-robin (id % 8); the LDS-DMA convolutions give every XCD one
+// contiguous range of pixel tiles (conv.hip xcd_major_id), so with the same order here a pixel's rows are produced and
+// consumed behind the same L2 all along the conv -> BatchNorm -> conv chain (option "bn_xcd", A/B in DESIGN.md section 8).
+__device__ __forceinline__ int bn_block_id(int xcd) {
+  const int id = blockIdx.x, n = gridDim.x;
+  if (!xcd) return id;
+  const int q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
 struct BnApplyArgs {
   const u16* x;
   u16* y;
@@ -167,6 +177,7 @@ struct BnApplyArgs {
   float eps, momentum;
   float* out_sums;        // [REPL][2][C] statistics of y (pre-zeroed) or nullptr
   int out_nchw;           // 1: y index = n*(C*HW) + c*HW + hw (the flatten order of the reference's fc input)
+  int xcd;                // 1: block -> row range in XCD-major order (bn_block_id)
 };
 
 // FLAGS (compile time, so that the streaming loop is one straight-line block): 1 PReLU, 2 residual,
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
   }
   load8(PRELU ? a.slope : nullptr, m.col * 8, 1.f, sl);
   __syncthreads();   // sh is reused below
-  const int64_t r0 = (int64_t)blockIdx.x * a.RB;
+  const int64_t r0 = (int64_t)bn_block_id(a.xcd) * a.RB;
   const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
   if (m.active) {
     // UF independent rows per iteration (all loads issued before any is consumed); 32-bit offsets from
@@ -291,6 +302,7 @@ struct BnBwdArgs {
   float* dbeta;
   float* dslope;
   int dy_nchw;            // dy laid out as the flatten order (see bn_apply out_nchw)
+  int xcd;                // 1: block -> row range in XCD-major order (bn_block_id)
 };
 
 __device__ __forceinline__ float load_dy_nchw(const BnBwdArgs& a, int64_t r, int c) {
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
       zo[j] = cb_[j] - c_mean[j] * c_is[j] * cg_[j];
     }
   }
-  const int64_t r0 = (int64_t)blockIdx.x * a.RB;
+  const int64_t r0 = (int64_t)bn_block_id(a.xcd) * a.RB;
   const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
   if (m.active) {
     const u16* x0 = a.x + r0 * C + m.col * 8;
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
       zo[j] = cb_[j] + xo * g;
     }
   }
-  const int64_t r0 = (int64_t)blockIdx.x * a.RB;
+  const int64_t r0 = (int64_t)bn_block_id(a.xcd) * a.RB;
   const int nrow = (int)((r0 + a.RB < a.M ? r0 + a.RB : a.M) - r0);
   const u16* x0 = a.x + r0 * C + m.col * 8;
   const u16* d0 = a.dy + r0 * C + m.col * 8;
@@ -713,6 +725,8 @@ inline int blocks_for(int64_t work_items, int per_block = 256, int cap = 2048) {
 
 extern "C" {
 
+int g_bn_xcd = 0;                // "bn_xcd": 1 = XCD-major block order in the BatchNorm kernels (bn_block_id); measured: no change
+                                 // (91.7 ms either way at ir100 / batch 256 — lines do not survive in L2 across kernel boundaries)
 int g_bn_block_bytes = 65536;   // bytes of x per block (vlsfr_set_option("bn_block_kb", v))
 
 static int bn_geom(int64_t M, int C, int* RB, int* nblk) {
@@ -751,7 +765,7 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, sums, gamma, beta, slope, (const u16*)residual, save_mean,
-                save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw};
+                save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw, g_bn_xcd && nblk >= 16};
   const int flags = (slope ? 1 : 0) | (residual ? 2 : 0) | (out_sums ? 4 : 0) | (out_nchw ? 8 : 0) | (relu_after ? 16 : 0);
   const dim3 grid(nblk), block(256);
   const size_t shb = 2 * C * sizeof(float);
@@ -776,7 +790,7 @@ int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
-              (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw};
+              (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw, g_bn_xcd && nblk >= 16};
   const int rflags = (slope ? 1 : 0) | (dy_nchw ? 2 : 0);
   const int aflags = rflags | (dx_add ? 4 : 0);
   const dim3 grid(nblk), block(256);
