@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
     ap.add_argument("--overlap-wgrad", action="store_true", help="A/B: weight gradients of each backward pass on a side stream "
                     "(vlsfr_iresnet_backward_overlap; measured slower, off by default)")
+    ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') around two steps")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, identity-sharded pool, "
+                    "partitioned SGD, every collective) even with one rank: rehearses the RCCL calls on a 1-GPU box")
     ap.add_argument("--head-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the e4m3 sweep of csrc/head8.hip (config C5's "
                     "precision for the class matmul; the backbone stays bf16)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: print the forward / backward / update split to stderr")
@@ -157,9 +160,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    dist_on = world > 1 or args.force_dist        # --force-dist: the N > 1 code path (RCCL collectives included) with one rank
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -173,7 +180,7 @@ def main():
 
     Q = args.queue or args.identities
     torch.manual_seed(1234)                                   # identical initial weights on every rank
-    sharded = world > 1 and args.pool == "sharded" and Q % world == 0
+    sharded = dist_on and args.pool == "sharded" and Q % world == 0
     # the pool is drawn straight into HBM in chunks (ffc.build_pool: same normalize(rand) semantics as
     # ffc.py:29-30); under the identity-sharded pool every rank builds only its own slots
     model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, pool_device=dev,
@@ -192,7 +199,7 @@ def main():
     cfg = dict(optim="SGD", scheduler="multistep", LR=0.1, momentum=0.9, decay=1e-4, nesterov=True, warmup=0, epochs=1,
                milestones=[8, 14, 17], gammas=[0.1, 0.1, 0.1])     # config/optim_config
     step_model = model
-    if world > 1:
+    if dist_on:
         # N > 1: partitioned SGD (each rank updates 1/N of the parameters; gradients reduce-scattered bucket by bucket
         # under the backward pass), behind the reference's scheduler interface
         from vlsfr_amd.optim.optimizer import WarmupSchedule
@@ -219,7 +226,7 @@ def main():
         if phases:
             ev[1].record()
         loss.backward()
-        if world > 1:
+        if dist_on:
             step_model.reduce_gradients(opt)
         if phases:
             ev[2].record()
@@ -242,6 +249,12 @@ def main():
         note("warm-up step %d done" % i)
     if dist is not None:
         dist.barrier()
+    if args.sync_debug:
+        torch.cuda.set_sync_debug_mode("warn")
+        for i in range(2):
+            one_step(args.warmup + i)
+        torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
     if args.phases:          # diagnostic: forward / backward / update split of the three-stream schedule (main-stream events)
         for i in range(4):
             one_step(args.warmup + i, phases=True)
@@ -315,7 +328,7 @@ def main():
         model.__dict__['concurrent_streams'] = True
         model.probe_net.concurrent_backward = True
         model.probe_net.overlap_wgrad = args.overlap_wgrad
-    loss_val = float(step_model.global_loss(loss)) if world > 1 else float(loss.detach())   # collective: every rank
+    loss_val = float(step_model.global_loss(loss)) if dist_on else float(loss.detach())   # collective: every rank
     if rank != 0:
         return
     # an event bracket reads the kernel plus the empty-bracket time measured above: take that out per launch
@@ -370,7 +383,7 @@ def main():
         "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
                                "(2 x %d faces per step per GPU), SGD-nesterov, %dx%d synthetic images" %
                                (args.net, args.identities, Q, args.feat, args.loss, B, B, hw, hw),
-                   "parallelism": ("dp%d" % world) + ("" if world == 1 else "+zero1-sgd+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")),
+                   "parallelism": ("dp%d" % world) + ("" if not dist_on else "+zero1-sgd+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")),
                    "loss": loss_val},
         "roofline": roofline,
     }

@@ -302,7 +302,7 @@ class ShardedDcpHead(object):
             self._ws_key = key
         pd, gd = p_all.detach().float().contiguous(), g_all.detach().float().contiguous()
         st = dict(tab_d=tab_d, plan=plan, cfg=cfg, pd=pd, gd=gd, transactional=transactional, thr=None,
-                  label=torch.from_numpy(tab[:B].copy()).to(dev))
+                  label=tab_d[:B])                      # pool_label block of the table (no second, blocking copy)
         if self.loss_type == "SV":
             base = tab_d.data_ptr()
             at = lambda k: ctypes.c_void_p(base + 4 * k * B)

@@ -108,6 +108,7 @@ class Comm(object):
 
 class DataParallelFFC(object):
     """Data-parallel backbones over a replicated pool; also the base of ShardedFFC (everything but the head)."""
+    overlap_head = False
 
     def __init__(self, model, dist):
         self.m = model
@@ -193,19 +194,50 @@ class DataParallelFFC(object):
     def _gather_rows(self, t):
         return self.comm.all_gather(t).reshape((-1,) + tuple(t.shape[1:]))
 
-    def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
-        m = self.m
-        head = m._ensure_head()
-        p, g = m.embed_pair(p_data, g_data, update_gallery=transactional)
+    def _head_pass(self, p, g, probe_label, gallery_label, transactional):
+        """Everything of a pass after the two backbones (collectives included); runs on the current stream."""
+        head = self.m._ensure_head()
         with torch.no_grad():
             g_all = self._gather_rows(g)
         return head.run_pass(p, g_all, probe_label, gallery_label, transactional, row_offset=self.rank * p.shape[0])
 
+    def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
+        p, g = self.m.embed_pair(p_data, g_data, update_gallery=transactional)
+        return self._head_pass(p, g, probe_label, gallery_label, transactional)
+
     def __call__(self, x, y, x_label, y_label):
         xl, yl = self.exchange_labels(x_label, y_label)
-        loss2 = self._pass(x, y, xl, yl, True)        # ffc.py:265
-        loss1 = self._pass(y, x, yl, xl, False)       # ffc.py:266
-        return loss1 + loss2
+        m = self.m
+        if not self.overlap_head or not m.__dict__.get('concurrent_streams', True) or not x.is_cuda:
+            loss2 = self._pass(x, y, xl, yl, True)        # ffc.py:265
+            loss1 = self._pass(y, x, yl, xl, False)       # ffc.py:266
+            return loss1 + loss2
+        # overlap_head (off by default): as FFC.forward, the head of the rollback pass (gather, sweep, combine: collectives
+        # included) on a head stream beside the backbones of the commit pass.  Both heads run on that one stream in program
+        # order, so pool / LRU state and the order of the collectives are those of the sequential schedule on every rank.
+        # Measured with one rank over RCCL (bench.py --force-dist, ir100 / 10 M identities): 106 ms per step against 102 ms
+        # with the heads on the main stream — the collectives' own stream and its event edges cost more than the overlap
+        # returns; revisit on a real multi-GPU node.
+        main = torch.cuda.current_stream()
+        hs = self.__dict__.get('_head_stream')
+        if hs is None or hs.device != main.device:
+            hs = self._head_stream = torch.cuda.Stream(device=main.device)
+        p1, g1 = m.embed_pair(x, y, update_gallery=True)
+        hs.wait_stream(main)
+        with torch.cuda.stream(hs):
+            loss2 = self._head_pass(p1, g1, xl, yl, True)
+        p1.record_stream(hs)
+        g1.record_stream(hs)
+        p2, g2 = m.embed_pair(y, x, update_gallery=False)
+        hs.wait_stream(main)
+        with torch.cuda.stream(hs):
+            loss1 = self._head_pass(p2, g2, yl, xl, False)
+            total = loss1 + loss2
+        p2.record_stream(hs)
+        g2.record_stream(hs)
+        main.wait_stream(hs)
+        total.record_stream(main)
+        return total
 
     def global_loss(self, loss):
         """Every rank returns its share of the loss (the shares sum to the reference loss); this is the sum."""
@@ -258,10 +290,8 @@ class ShardedFFC(DataParallelFFC):
         self.head.lru.restore_arrays(st["lru_keys"].numpy(), st["lru_slots"].numpy())
         self.head.qp[:] = st["qp"].numpy()
 
-    def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
+    def _head_pass(self, p, g, probe_label, gallery_label, transactional):
         from .head import _HeadFn
-        m = self.m
-        p, g = m.embed_pair(p_data, g_data, update_gallery=transactional)
         B, D = p.shape
         with torch.no_grad():
             pg = self._gather_rows(torch.cat([p.detach(), g], dim=1))        # ONE all-gather: [W * B, 2 D]
