@@ -256,9 +256,16 @@ def main():
         torch.cuda.set_sync_debug_mode("default")
         torch.cuda.synchronize()
     if args.phases:          # diagnostic: forward / backward / update split of the three-stream schedule (main-stream events)
+        step_model.__dict__["_marks"] = []
         for i in range(4):
             one_step(args.warmup + i, phases=True)
         torch.cuda.synchronize()
+        marks = step_model.__dict__.pop("_marks", None) if hasattr(step_model, "__dict__") else None
+        if marks:
+            per = len(marks) // 4
+            for k in range(1, per):
+                note("  forward segment %-44s %.2f ms" % (marks[k][0], sum(marks[s * per + k - 1][1].elapsed_time(marks[s * per + k][1])
+                                                                          for s in range(1, 4)) / 3))
         for k, nm in enumerate(("forward (2 passes + heads)", "backward (2 passes)", "optimizer + EMA")):
             note("phase %-28s %.2f ms" % (nm, sum(e[k].elapsed_time(e[k + 1]) for e in phase_ev[1:]) / (len(phase_ev) - 1)))
     L.vlsfr_profile_reset()

@@ -186,13 +186,24 @@ class FFC(Module):
         if hs is None or hs.device != main.device:
             hs = torch.cuda.Stream(device=main.device)
             self.__dict__['_head_stream'] = hs
+        marks = self.__dict__.get('_marks')          # diagnostic: bench.py --phases (main-stream events)
+
+        def mark(name):
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+
+        mark("start")
         p1, g1 = self.embed_pair(x, y, update_gallery=True)
+        mark("backbones of pass 1")
         hs.wait_stream(main)
         with torch.cuda.stream(hs):
             loss2 = head.run_pass(p1, g1, x_label, y_label, transactional=True)
         p1.record_stream(hs)
         g1.record_stream(hs)
         p2, g2 = self.embed_pair(y, x, update_gallery=False)
+        mark("backbones of pass 2 (head 1 beside them)")
         hs.wait_stream(main)
         with torch.cuda.stream(hs):
             loss1 = head.run_pass(p2, g2, y_label, x_label, transactional=False)
@@ -200,6 +211,7 @@ class FFC(Module):
         p2.record_stream(hs)
         g2.record_stream(hs)
         main.wait_stream(hs)
+        mark("head 2")
         total.record_stream(main)
         return total
 

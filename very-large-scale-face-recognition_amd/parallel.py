@@ -27,6 +27,7 @@ The N > 1 path has been exercised with 2 ranks over gloo (CPU tests; one-GPU reh
 RCCL itself runs in the driver's multi-GPU bench only (no multi-GPU box is available to the build).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -42,11 +43,16 @@ class Comm(object):
         self.dist, self.group = dist, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.rccl = dist.get_backend(group) == "nccl"
+        # diagnostic (VLSFR_COMM_SOLO=1, one rank): collectives become local copies — separates what the collectives cost
+        # from what the rest of the distributed step costs
+        self.solo = self.world == 1 and os.environ.get("VLSFR_COMM_SOLO", "0") == "1"
 
     def _host(self, t):
         return t if not t.is_cuda or self.rccl else t.cpu()
 
     def broadcast(self, t, src=0):
+        if self.solo:
+            return t
         c = self._host(t)
         self.dist.broadcast(c, src=src, group=self.group)
         if c is not t:
@@ -55,6 +61,8 @@ class Comm(object):
 
     def all_reduce(self, t, op="sum"):
         rop = self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM
+        if self.solo:
+            return t
         c = self._host(t)
         self.dist.all_reduce(c, op=rop, group=self.group)
         if c is not t:
@@ -64,6 +72,8 @@ class Comm(object):
     def all_gather(self, t):
         """-> [world, *t.shape]"""
         t = t.contiguous()
+        if self.solo:
+            return t.unsqueeze(0).clone()
         if self.rccl or not t.is_cuda:
             out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
             if self.rccl:
@@ -77,6 +87,9 @@ class Comm(object):
 
     def all_gather_into(self, out, shard):
         """out (flat, world * shard.numel()) <- concatenation of every rank's shard."""
+        if self.solo:
+            out.copy_(shard.reshape(-1))
+            return out
         if self.rccl:
             self.dist.all_gather_into_tensor(out, shard, group=self.group)
             return out
@@ -85,6 +98,9 @@ class Comm(object):
 
     def reduce_scatter_sum(self, out, inp):
         """out <- this rank's 1/world slice (along dim 0) of the sum of `inp` over the ranks."""
+        if self.solo:
+            out.copy_(inp)
+            return out
         if self.rccl:
             self.dist.reduce_scatter_tensor(out, inp, group=self.group)
             return out
@@ -119,6 +135,18 @@ class DataParallelFFC(object):
         self.cpu_group = dist.new_group(backend="gloo")        # labels (host arrays) travel here, see module docstring
         self._labels = None
         self._comm_stream = None
+        # The step's own side streams are created BEFORE the first collective creates RCCL's: HIP deals streams to its
+        # (few) hardware queues in creation order, and two streams on one queue run one after the other — the gallery
+        # pass, the head sweep and the second backward pass must not end up behind a collective's stream.
+        if torch.cuda.is_available() and next(model.parameters()).is_cuda:
+            d = next(model.parameters()).device
+            if model.__dict__.get('_side_stream') is None:
+                model.__dict__['_side_stream'] = torch.cuda.Stream(device=d)
+            self._head_stream = torch.cuda.Stream(device=d)
+            pn = getattr(model, "probe_net", None)
+            if pn is not None and hasattr(pn, "_side_stream") and callable(pn._side_stream):
+                pn._side_stream(d)
+            self._comm_stream = torch.cuda.Stream(device=d)
         # identical starting point on every rank (a pool built shard-local is already consistent by construction)
         pre_sharded = getattr(model, 'pool_shard', None) is not None
         for t in list(model.parameters()) + [b for n, b in model.named_buffers() if not (pre_sharded and n == 'queue')]:
@@ -289,6 +317,76 @@ class ShardedFFC(DataParallelFFC):
         self.head.lru.reset()
         self.head.lru.restore_arrays(st["lru_keys"].numpy(), st["lru_slots"].numpy())
         self.head.qp[:] = st["qp"].numpy()
+
+    overlap_head = False
+
+    def __call__(self, x, y, x_label, y_label):
+        """overlap_head = True: the step with the SWEEP of the rollback pass (the one multi-millisecond kernel of the head,
+        no collective in it) on a head stream beside the backbones of the commit pass; every collective stays on the main
+        stream in the sequential schedule's order.  Off by default: with one rank over RCCL (bench.py --force-dist --phases)
+        the sweep does run beside the backbones but lengthens them by its own duration (both are MFMA-bound: 24.5 + 29.2 +
+        5.3 ms against 24.5 + 24.5 + 2 x 5.3 sequential), and the step measured 106.9 ms against 103.0 ms."""
+        m = self.m
+        if not self.overlap_head or not m.__dict__.get('concurrent_streams', True) or not x.is_cuda:
+            return super(ShardedFFC, self).__call__(x, y, x_label, y_label)
+        from .head import _HeadFn
+        xl, yl = self.exchange_labels(x_label, y_label)
+        head, comm = self.head, self.comm
+        main = torch.cuda.current_stream()
+        hs = self.__dict__.get('_head_stream')
+        if hs is None or hs.device != main.device:
+            hs = self._head_stream = torch.cuda.Stream(device=main.device)
+
+        def gather(p, g):
+            D = p.shape[1]
+            with torch.no_grad():
+                pg = self._gather_rows(torch.cat([p.detach(), g], dim=1))
+                return pg[:, :D].contiguous(), pg[:, D:].contiguous()
+
+        def begin(p_all, g_all, pl, gl, transactional):
+            st = head.begin(p_all, g_all, pl, gl, transactional)
+            if st["thr"] is not None:
+                st["thr"] = comm.all_reduce_max(st["thr"])
+            return st
+
+        def tail(st, p):
+            B = p.shape[0]
+            st = head.combine(st, comm, own_rows=(self.rank * B, (self.rank + 1) * B))
+            loss, dP = head.finish(st)
+            return _HeadFn.apply(p, loss.reshape(()), dP.contiguous())
+
+        marks = self.__dict__.get('_marks')                             # diagnostic: bench.py --phases (main-stream events)
+
+        def mark(name):
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+
+        mark("start")
+        p1, g1 = m.embed_pair(x, y, update_gallery=True)
+        mark("backbones of pass 1")
+        st1 = begin(*gather(p1, g1), xl, yl, True)                       # ffc.py:265 (bookkeeping incl. its rollback)
+        mark("gather + bookkeeping 1")
+        before = set(id(v) for v in st1.values() if torch.is_tensor(v))
+        hs.wait_stream(main)
+        with torch.cuda.stream(hs):
+            st1 = head.sweep(st1)
+        for v in st1.values():
+            if torch.is_tensor(v):
+                v.record_stream(main if id(v) not in before else hs)
+        p2, g2 = m.embed_pair(y, x, update_gallery=False)
+        mark("backbones of pass 2 (sweep 1 beside them)")
+        pa2, ga2 = gather(p2, g2)
+        main.wait_stream(hs)
+        mark("gather 2 + join of sweep 1")
+        loss2 = tail(st1, p1)
+        mark("combine + finish 1")
+        st2 = head.sweep(begin(pa2, ga2, yl, xl, False))                 # ffc.py:266
+        mark("bookkeeping + sweep 2")
+        loss1 = tail(st2, p2)
+        mark("combine + finish 2")
+        return loss1 + loss2
 
     def _head_pass(self, p, g, probe_label, gallery_label, transactional):
         from .head import _HeadFn
