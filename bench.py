@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
     ap.add_argument("--overlap-wgrad", action="store_true", help="A/B: weight gradients of each backward pass on a side stream "
                     "(vlsfr_iresnet_backward_overlap; measured slower, off by default)")
+    ap.add_argument("--counters-only", action="store_true", help="stop after the timed region (for rocprofv3 --pmc passes: per-launch "
+                    "HIP events from several host threads under counter collection crashed the profiler)")
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') around two steps")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, identity-sharded pool, "
                     "partitioned SGD, every collective) even with one rank: rehearses the RCCL calls on a 1-GPU box")
@@ -303,6 +305,11 @@ def main():
         L.vlsfr_profile_reset()
         return out
 
+    if args.counters_only:   # rocprofv3 --pmc passes: the K timed steps are all that is wanted (no HIP events anywhere)
+        if rank == 0:
+            print(json.dumps({"value": round(world * 2 * B * args.steps / dt, 2), "unit": "faces/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "note": "--counters-only run: no roofline legs"}), flush=True)
+        return
     L.vlsfr_profile_event_overhead_us.restype = ctypes.c_double
     ev_us = float(L.vlsfr_profile_event_overhead_us(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     if not args.timed_profile:
@@ -371,11 +378,11 @@ def main():
     # process, so the figure measured by rocprofv3 --pmc on this same command (profiles/) is attached
     # when the configuration matches
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02f_pmc_traffic.json")) as f:
             pt = json.load(f)
         if pt["config"] == {"net": args.net, "batch": B, "identities": args.identities}:
             roofline["traffic"] = pt["kernels"][dom.replace("_kernel", "")]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            roofline["traffic_source"] = "profiles/r02f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     except (OSError, KeyError, ValueError):
         pass
     faces = world * 2 * B * args.steps
