@@ -148,7 +148,9 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
-    torch.set_num_threads(host_threads())
+    _skip = os.environ.get("BENCH_SKIP", "").split(",")      # diagnostic A/B switches
+    if "threads" not in _skip:
+        torch.set_num_threads(host_threads())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -169,6 +171,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        # torch's stream pool comes to life BEFORE RCCL creates its streams: HIP deals its few hardware queues to streams in
+        # creation order, and with the communicator's streams first the step's side streams (gallery pass, second backward
+        # pass) landed on queues they had to share — 101 ms per step instead of 92.6 with one rank (BENCH_SKIP=late_streams
+        # restores that order for an A/B).
+        from vlsfr_amd.parallel import warm_stream_pool
+        if "late_streams" not in _skip:
+            warm_stream_pool(dev)
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

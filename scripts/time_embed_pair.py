@@ -53,6 +53,23 @@ if not dist.is_initialized():
 from vlsfr_amd.parallel import ShardedFFC
 sm = ShardedFFC(m, dist)
 timeit("(c) process group + ShardedFFC wrapper")
+# one full distributed step (forward, backward, bucket reduce-scatters, partitioned update), then the pair again
+lab = torch.from_numpy(np.random.default_rng(0).choice(60000, size=B, replace=False).astype(np.int64))
+opt2 = sm.make_optimizer(0.1, 0.9, 1e-4, True) if "own_opt" in sys.argv else opt
+for it in range(2):
+    opt2.zero_grad()
+    loss = sm(x, y, lab, lab)
+    loss.backward()
+    if hasattr(opt2, "reduce_bucket") and hasattr(opt2.comm, "dist"):
+        sm.reduce_gradients(opt2)
+    opt2.step()
+torch.cuda.synchronize()
+timeit("(c2) after two full distributed steps")
+import gc
+del loss
+gc.collect()
+torch.cuda.synchronize()
+timeit("(c3) after dropping the last loss / graph")
 pn.__dict__["signal_stages"] = False
 timeit("(d) same, signal_stages off")
 dist.destroy_process_group()

@@ -163,6 +163,8 @@ def train(conf, log=print):
     if world > 1:
         import torch.distributed as dist
         if not dist.is_initialized():
+            from .parallel import warm_stream_pool
+            warm_stream_pool(dev)                                      # before RCCL's streams exist, see its docstring
             backend = getattr(conf, "dist_backend", "nccl")            # "gloo": rehearsal on one GPU (tests), host-staged
             dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
     torch.manual_seed(0)

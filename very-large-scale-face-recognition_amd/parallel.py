@@ -35,6 +35,20 @@ import torch
 from . import _lib
 
 
+def warm_stream_pool(device, n=4):
+    """Call BEFORE torch.distributed.init_process_group(..., device_id=...): creates torch's stream pool (and runs one tiny
+    kernel on a few of its streams) so that the hardware queues HIP deals out in creation order go to the streams the step
+    uses side by side, not to the communicator's.  Measured with one rank over RCCL, ir100 / 10 M identities / batch 256:
+    92.6 ms per step with the pool first, 101 ms with RCCL's streams first."""
+    if not torch.cuda.is_available():
+        return
+    streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+    for st in streams:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=device)
+    torch.cuda.synchronize(device)
+
+
 class Comm(object):
     """The collectives of the step on device tensors.  Backend "nccl" (= RCCL on ROCm) runs them in place; under
     gloo (CPU tests, the 2-rank rehearsal on a 1-GPU box) the same calls stage through host memory."""
@@ -124,7 +138,7 @@ class Comm(object):
 
 class DataParallelFFC(object):
     """Data-parallel backbones over a replicated pool; also the base of ShardedFFC (everything but the head)."""
-    overlap_head = False
+    overlap_head = os.environ.get("VLSFR_OVERLAP_HEAD", "0") == "1"
 
     def __init__(self, model, dist):
         self.m = model
@@ -229,9 +243,21 @@ class DataParallelFFC(object):
             g_all = self._gather_rows(g)
         return head.run_pass(p, g_all, probe_label, gallery_label, transactional, row_offset=self.rank * p.shape[0])
 
+    def _mark(self, name):
+        marks = self.__dict__.get('_marks')          # diagnostic: bench.py --phases (main-stream events)
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+
     def _pass(self, p_data, g_data, probe_label, gallery_label, transactional):
+        self._mark("start" if transactional else "head of pass 1")
         p, g = self.m.embed_pair(p_data, g_data, update_gallery=transactional)
-        return self._head_pass(p, g, probe_label, gallery_label, transactional)
+        self._mark("backbones of pass %d" % (1 if transactional else 2))
+        out = self._head_pass(p, g, probe_label, gallery_label, transactional)
+        if not transactional:
+            self._mark("head of pass 2")
+        return out
 
     def __call__(self, x, y, x_label, y_label):
         xl, yl = self.exchange_labels(x_label, y_label)
@@ -240,12 +266,12 @@ class DataParallelFFC(object):
             loss2 = self._pass(x, y, xl, yl, True)        # ffc.py:265
             loss1 = self._pass(y, x, yl, xl, False)       # ffc.py:266
             return loss1 + loss2
-        # overlap_head (off by default): as FFC.forward, the head of the rollback pass (gather, sweep, combine: collectives
-        # included) on a head stream beside the backbones of the commit pass.  Both heads run on that one stream in program
-        # order, so pool / LRU state and the order of the collectives are those of the sequential schedule on every rank.
-        # Measured with one rank over RCCL (bench.py --force-dist, ir100 / 10 M identities): 106 ms per step against 102 ms
-        # with the heads on the main stream — the collectives' own stream and its event edges cost more than the overlap
-        # returns; revisit on a real multi-GPU node.
+        # overlap_head (VLSFR_OVERLAP_HEAD=1; off by default): as FFC.forward, the head of the rollback pass (gather, sweep,
+        # combine: collectives included) on a head stream beside the backbones of the commit pass.  Both heads run on that
+        # one stream in program order, so pool / LRU state and the order of the collectives are those of the sequential
+        # schedule on every rank.  Measured with one rank over RCCL (bench.py --force-dist, ir100 / 10 M identities):
+        # 92.5-95.0 ms per step against 92.1-92.3 with the heads on the main stream — sweep and backbones are both
+        # MFMA-bound, running them side by side returns nothing.
         main = torch.cuda.current_stream()
         hs = self.__dict__.get('_head_stream')
         if hs is None or hs.device != main.device:
@@ -318,14 +344,13 @@ class ShardedFFC(DataParallelFFC):
         self.head.lru.restore_arrays(st["lru_keys"].numpy(), st["lru_slots"].numpy())
         self.head.qp[:] = st["qp"].numpy()
 
-    overlap_head = False
+    overlap_head = os.environ.get("VLSFR_OVERLAP_HEAD", "0") == "1"
 
     def __call__(self, x, y, x_label, y_label):
         """overlap_head = True: the step with the SWEEP of the rollback pass (the one multi-millisecond kernel of the head,
         no collective in it) on a head stream beside the backbones of the commit pass; every collective stays on the main
-        stream in the sequential schedule's order.  Off by default: with one rank over RCCL (bench.py --force-dist --phases)
-        the sweep does run beside the backbones but lengthens them by its own duration (both are MFMA-bound: 24.5 + 29.2 +
-        5.3 ms against 24.5 + 24.5 + 2 x 5.3 sequential), and the step measured 106.9 ms against 103.0 ms."""
+        stream in the sequential schedule's order.  Off by default: with one rank over RCCL (bench.py --force-dist) 92.5-93.0 ms
+        per step against 92.3 ms sequential (the sweep lengthens the MFMA-bound backbones beside it by its own duration)."""
         m = self.m
         if not self.overlap_head or not m.__dict__.get('concurrent_streams', True) or not x.is_cuda:
             return super(ShardedFFC, self).__call__(x, y, x_label, y_label)
