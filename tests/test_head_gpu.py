@@ -494,3 +494,38 @@ def test_head_fp8_vs_oracle(loss_type, margin, Q, B, n_id):
     assert head.lru.state_dict() == lru.state_dict()
     assert head.qp.tolist() == qp
     np.testing.assert_array_equal(head.queue.cpu().numpy(), queue.float().numpy())
+
+
+@pytest.mark.parametrize("loss_type,margin,n_id", [("Arc", 0.5, 12000), ("SV", 0.35, 40000)])
+def test_identity_sharded_head_world8_fp8(loss_type, margin, n_id):
+    """C5's precision on the node size the metric is quoted on: eight simulated ranks, each sweeping the e4m3 shadow of ITS
+    slots for all rows; the combined result equals the single-pool fp8 head up to summation order (shards are tile-aligned,
+    so every numerator is quantised against the same half-tile maximum), hard-negative candidates re-scored in fp32 on the
+    owning rank; the shards' shadows are the slices of the whole pool's."""
+    from vlsfr_amd.head import ShardedDcpHead
+    Q, D, B, T, world = 32768, 512, 64, 2, 8
+    case = common.head_case(4200, Q, D, B, T, n_id)
+    full = make_head(case["queue0"], loss_type, 32.0, margin, False)
+    full.head_dtype = "fp8"
+    q0 = torch.from_numpy(case["queue0"]).cuda()
+    Qs = Q // world
+    shards = [ShardedDcpHead(q0[:, r * Qs:(r + 1) * Qs].contiguous(), r, world, Q, 32.0, margin, loss_type, precise=False)
+              for r in range(world)]
+    for h in shards:
+        h.head_dtype = "fp8"
+    for t in range(T):
+        xl, yl = case["XL"][t], case["YL"][t]
+        for s_, (pl, gl, trans) in enumerate(((xl, yl, True), (yl, xl, False))):
+            g = torch.from_numpy(case["G"][t, s_]).cuda()
+            p = torch.from_numpy(case["P"][t, s_]).cuda().requires_grad_(True)
+            loss = full.run_pass(p, g, pl, gl, trans)
+            loss.backward()
+            for l, dP in _sharded_pass(shards, p.detach(), g, pl, gl, trans):
+                np.testing.assert_allclose(float(l), float(loss.detach()), rtol=1e-4, atol=1e-5)
+                np.testing.assert_allclose(dP.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-3,
+                                           atol=2e-4 * float(p.grad.abs().max()))
+    assert all(h.shadow.t.get("fp8") is not None and h.shadow.t.get("bf16") is None for h in shards)
+    assert torch.equal(torch.cat([h.queue for h in shards], dim=1), full.queue)
+    assert torch.equal(torch.cat([h.shadow.t["fp8"] for h in shards], dim=0), full.shadow.t["fp8"])
+    for h in shards:
+        assert h.lru.state_dict() == full.lru.state_dict() and h.qp.tolist() == full.qp.tolist()
