@@ -374,6 +374,7 @@ __device__ __forceinline__ const float* special_vec(const float* g, const float*
   return queue + ((size_t)Q + col) * D;
 }
 
+constexpr int SPECIAL_ROWS = 128;
 __global__ __launch_bounds__(256) void head_special_kernel(SpecialArgs a) {
   const int s = blockIdx.x;
   const int col = a.special_col[s] - a.slot_lo;
@@ -382,7 +383,10 @@ __global__ __launch_bounds__(256) void head_special_kernel(SpecialArgs a) {
   const float* v1 = special_vec(a.g, a.queue, a.Q, a.D, col, s1);
   const float* v2 = special_vec(a.g, a.queue, a.Q, a.D, col, s2);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = wave; i < a.B; i += 4) {
+  // blockIdx.y: chunk of SPECIAL_ROWS probe rows (an 8-rank batch has 2048 rows: one block per column would walk them
+  // 512 dependent dot products deep)
+  const int i_end = ((int)blockIdx.y + 1) * SPECIAL_ROWS < a.B ? ((int)blockIdx.y + 1) * SPECIAL_ROWS : a.B;
+  for (int i = (int)blockIdx.y * SPECIAL_ROWS + wave; i < i_end; i += 4) {
     float d1 = 0.f, d2 = 0.f;
     for (int d = lane; d < a.D; d += 64) {
       const float pv = a.p[(size_t)i * a.D + d];
@@ -736,11 +740,29 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
   const int nw_lds = a.n_chunks > a.n_special ? a.n_chunks : a.n_special;
   const float** vptr = (const float**)(wts + ((nw_lds + 1) & ~1));
   float* wsum = (float*)(vptr + a.n_special);   // [4][D] per-wave partial sums   // [n_special]
+  int* own = (int*)(wsum + 4 * D);              // [n_special]: indices of the special columns this rank owns, ascending
   const int label = a.pool_label[i];
   const float qs = a.scale * LOG2E;
   const int lo = sa.slot_lo, hi = sa.slot_lo + (int)a.Q;
   __shared__ int sh_idx[1];
   auto owned = [&](int s) { const int c = a.special_col[s]; return c >= lo && c < hi; };
+  // Stable compaction of the owned special columns (one wave, ballot prefix): with W ranks only ~1/W of the table is
+  // owned here, and every loop below walks the compact list instead of the whole table (the combine of an 8-rank batch
+  // read 8x the class vectors it needed, with weight zero).
+  __shared__ int sh_nown[1];
+  if (wave == 0) {
+    int n = 0;
+    for (int s0 = 0; s0 < a.n_special; s0 += 64) {
+      const int s = s0 + lane;
+      const bool o = s < a.n_special && owned(s);
+      const unsigned long long m = __ballot(o);
+      if (o) own[n + __popcll(m & ((1ull << lane) - 1ull))] = s;
+      n += __popcll(m);
+    }
+    if (lane == 0) sh_nown[0] = n;
+  }
+  __syncthreads();
+  const int n_own = sh_nown[0];
   auto block_max = [&](float v) -> float {
     v = wave_max(v);
     if (lane == 0) red[wave] = v;
@@ -798,8 +820,7 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       }
       float mx = NEG_BIG;
       for (int c = tid; c < a.n_chunks; c += 256) mx = fmaxf(mx, a.part_m[v][(size_t)c * a.Bp + i]);
-      for (int s = tid; s < a.n_special; s += 256)
-        if (owned(s)) mx = fmaxf(mx, cmod(s) * qs);
+      for (int k = tid; k < n_own; k += 256) mx = fmaxf(mx, cmod(own[k]) * qs);
       const float M = block_max(mx);
       float lsum = 0.f;
       for (int c = tid; c < a.n_chunks; c += 256) {
@@ -807,8 +828,7 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
         wts[c] = w;
         lsum += w * a.part_l[v][(size_t)c * a.Bp + i];
       }
-      for (int s = tid; s < a.n_special; s += 256)
-        if (owned(s)) lsum += exp2f(cmod(s) * qs - M);
+      for (int k = tid; k < n_own; k += 256) lsum += exp2f(cmod(own[k]) * qs - M);
       const float L = block_sum(lsum);
       float* O = sa.out_O + ((size_t)i * 2 + v) * D;
       float* T = sa.out_T + ((size_t)i * 2 + v) * D;
@@ -818,14 +838,13 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
         T[d] = 0.f;
       }
       __syncthreads();
-      for (int s = tid; s < a.n_special; s += 256) {
-        const bool own = owned(s);
-        wts[s] = own ? exp2f(cmod(s) * qs - M) * cfac(s) : 0.f;
-        // columns of other ranks get weight 0 and a harmless in-range address (their g row or slot 0)
-        vptr[s] = special_vec(a.g, a.queue, a.Q, D, own ? a.special_col[s] - lo : 0, own ? src[s] : -1);
+      for (int k = tid; k < n_own; k += 256) {
+        const int s = own[k];
+        wts[k] = exp2f(cmod(s) * qs - M) * cfac(s);
+        vptr[k] = special_vec(a.g, a.queue, a.Q, D, a.special_col[s] - lo, src[s]);
       }
       __syncthreads();
-      combine_rows(vptr, wts, a.n_special, D, wsum);
+      combine_rows(vptr, wts, n_own, D, wsum);
       for (int d = tid; d < D; d += 256) O[d] += (wsum[d] + wsum[D + d]) + (wsum[2 * D + d] + wsum[3 * D + d]);
       __syncthreads();
       if (st >= 0) {
@@ -868,8 +887,7 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
           const size_t off = ((chunk * a.Bp + i) * 4) * KTOP + rest;
           if (a.topk_idx[off] >= 0) consider(a.topk_val[off], (long long)a.topk_idx[off] + lo);
         }
-        for (int s = tid; s < a.n_special; s += 256)
-          if (owned(s)) consider(cs[s], (long long)a.special_col[s]);
+        for (int k2 = tid; k2 < n_own; k2 += 256) consider(cs[own[k2]], (long long)a.special_col[own[k2]]);
         for (int o = 32; o > 0; o >>= 1) {
           const float ov = __shfl_xor(bv, o, 64);
           const long long ok = __shfl_xor(bk, o, 64);
@@ -1316,7 +1334,7 @@ int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g
 
   if (n_special > 0) {
     SpecialArgs sa{p, g, queue, cfg->Q, B, D, n_special, special_col, src1, src2, cos1, cos2, cfg->slot_lo};
-    hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(head_special_kernel, dim3(n_special, (B + SPECIAL_ROWS - 1) / SPECIAL_ROWS), dim3(256), 0, st, sa);
     VLSFR_HIP_CHECK_LAUNCH("head_special launch");
   }
   const bool sv = cfg->loss_type == 2;
@@ -1416,7 +1434,7 @@ static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const f
   float* cos2 = (float*)(ws + pl.off_cos2);
   if (n_special > 0) {
     SpecialArgs sa{p, g, queue, cfg->Q, B, D, n_special, special_col, src1, src2, cos1, cos2, cfg->slot_lo};
-    hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(head_special_kernel, dim3(n_special, (B + SPECIAL_ROWS - 1) / SPECIAL_ROWS), dim3(256), 0, st, sa);
     VLSFR_HIP_CHECK_LAUNCH("head_special launch");
   }
   SweepArgs a;
@@ -1492,7 +1510,7 @@ static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const f
   sf.cand_col = cand_col;
   sf.sv_thr = sv ? thr : nullptr;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
-  const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + (size_t)4 * D * 4 + 16;
+  const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + (size_t)4 * D * 4 + (size_t)n_special * 4 + 16;
   if (lds_f > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish_shard: too many special columns for one LDS image");
   if (lds_f > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)head_finish_shard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1541,7 +1559,7 @@ int vlsfr_head_shard_sv_thr(const vlsfr_head_cfg* cfg, const float* p, const flo
   float* cos2 = (float*)(ws + pl.off_cos2);
   if (n_special > 0) {
     SpecialArgs sa{p, g, queue, cfg->Q, B, cfg->D, n_special, special_col, src1, src2, cos1, cos2, cfg->slot_lo};
-    hipLaunchKernelGGL(head_special_kernel, dim3(n_special), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(head_special_kernel, dim3(n_special, (B + SPECIAL_ROWS - 1) / SPECIAL_ROWS), dim3(256), 0, st, sa);
     VLSFR_HIP_CHECK_LAUNCH("head_special launch");
   }
   hipLaunchKernelGGL(head_sv_thr_shard_kernel, dim3((B + 255) / 256), dim3(256), 0, st, pool_label, special_col, n_special, B,
