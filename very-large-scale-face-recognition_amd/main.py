@@ -173,6 +173,8 @@ def train(conf, log=print):
                   conf.neg_margin, conf.pretrained_model_path, conf.num_class,           # main.py:116-117
                   pool_device=dev if world > 1 else None,                                # N > 1: no rank ever builds or
                   pool_shard=(int(os.environ.get("RANK", "0")), world) if sharded else None).cuda()   # holds the whole pool
+    if getattr(conf, "head_dtype", "bf16") != "bf16":
+        ffc_net.head_dtype = conf.head_dtype                                             # "fp8": the e4m3 class matmul (config C5)
     optim_config = load_config(conf.optim_config) if conf.optim_config else dict(OPTIM_CONFIG)
     step_model = ffc_net
     start_iter = 0
@@ -245,6 +247,8 @@ def parse_args(argv=None):
     conf.add_argument('--data_store', type=str, default='', help='comma-separated FaceStore directories (data.py; the reference '
                       'hard-codes its LMDB paths at main.py:168-169); empty = synthetic batches')
     conf.add_argument('--data_kv', type=str, default='', help='the kv files of --data_store ("<key> <label>" lines)')
+    conf.add_argument('--head_dtype', type=str, default='bf16', choices=['bf16', 'fp8'],
+                      help='operand type of the class matmul (fp8: e4m3 shadow of the pool, csrc/head8.hip)')
     conf.add_argument('--dist_backend', type=str, default='nccl', choices=['nccl', 'gloo'])
     conf.add_argument('--pool', type=str, default='sharded', choices=['sharded', 'replicated'],
                       help='N > 1: identity-sharded pool (default) or a full replica per rank')
