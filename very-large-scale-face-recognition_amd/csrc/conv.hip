@@ -71,6 +71,7 @@ int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace s
 int g_wgrad_round_up = 0;    // "wgrad_round_up": 1 = round the slice count up (may exceed wgrad_target_wgs), the round-1 rule
 int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
+int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
@@ -89,6 +90,14 @@ struct ConvArgs {
   float* stats;      // optional [VLSFR_BN_REPL][2][Mrows] BatchNorm statistics of the rounded output
   long long* trace;  // diagnostics: per-phase clock stamps of waves 0 and 4 of one workgroup (vlsfr_conv_trace), or nullptr
   int gx = 0, gy = 0, xcd = 0;   // xcd != 0: launched as a 1-D grid of gx * gy * splitk workgroups in XCD-major order (xcd_major_id)
+  // Parity-class launch of a stride-2 input gradient (vlsfr_conv2d_dgrad): the input positions (2 h' + ph, 2 w' + pw) of one
+  // parity class see a stride-1 convolution of dY with the 1, 2 or 4 filter taps of matching parity, so each class is run
+  // as a forward-mode gather over the dY grid with a subset of a virtual 3 x 3 (or 1 x 1) filter and its rows scattered
+  // with stride 2 — the taps a position cannot see are never fetched or multiplied (they were 3/4 of the old kernel's work).
+  unsigned tap_mask = 0;          // virtual taps present (bit r' * S + s'); 0: every tap (ordinary launch)
+  unsigned long long tap_w = 0;   // 4 bits per virtual tap: the tap of the weight matrix it multiplies
+  int cls = 0;                    // 0: dense output rows p; 1 + 2 ph + pw: row of pixel (n, h', w') = (n Hf + 2 h' + ph) Wf + 2 w' + pw
+  int Hf = 0, Wf = 0;
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (id % 8), and each XCD has its own L2.  This maps
@@ -327,7 +336,35 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   // is issue-bound, not bandwidth-bound).
   static_assert(NT % 2 == 0, "pixel tiles are stored in pairs");
   const bool odd = h & 1;
-  u16* yrow = (u16*)a.y + (size_t)pw * a.Mrows + (mw - 4 * (h & 1));
+  // output row of the pixel tile this lane stores in pair jp (tile 2 jp + odd): the pixel index itself, or — parity-class
+  // launch — the position (n, 2 h' + ph, 2 w' + pw) of pixel (n, h', w') of the class grid, advanced 32 pixels per pair
+  // by carries (one division pair per lane)
+  int64_t orow[NT / 2];
+  if (a.cls) {
+    const int ph = (a.cls - 1) >> 1, pwc = (a.cls - 1) & 1;
+    const int q = pw + (odd ? 16 : 0);
+    const int HWc = a.Ho * a.Wo;
+    int n = q / HWc;
+    const int rem = q - n * HWc;
+    int hh = rem / a.Wo;
+    int ww = rem - hh * a.Wo;
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) {
+      orow[jp] = ((int64_t)n * a.Hf + 2 * hh + ph) * a.Wf + 2 * ww + pwc;
+      ww += 32;
+      while (ww >= a.Wo) {
+        ww -= a.Wo;
+        if (++hh >= a.Ho) {
+          hh = 0;
+          ++n;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) orow[jp] = pw + (2 * jp + (odd ? 1 : 0)) * 16;
+  }
+  u16* ybase = (u16*)a.y + (mw - 4 * (h & 1));
   auto store = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -356,7 +393,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         const int j = 2 * jp + (odd ? 1 : 0);
         const bool okst = FULL || (pw + j * 16 < P && mw - 4 * (h & 1) + i * 16 < a.Mrows);
-        if (okst) *(uint4*)(yrow + (size_t)j * 16 * a.Mrows + i * 16) = v;
+        if (okst) *(uint4*)(ybase + (size_t)orow[jp] * a.Mrows + i * 16) = v;
       }
     }
   };
@@ -435,7 +472,13 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   }
   const int m0 = by * BM;
   const int p0 = bx * BN;
-  const int nkt = K / BK;
+  // taps of the filter this launch walks: all R * S of them, or the subset of a parity-class launch
+  const int ntap_all = a.R * a.S;
+  unsigned long long tap_list = 0;   // 4 bits per entry: virtual tap ids in ascending order
+  int ntap = 0;
+  for (int t = 0; t < ntap_all; ++t)
+    if (!a.tap_mask || ((a.tap_mask >> t) & 1u)) tap_list |= (unsigned long long)t << (4 * ntap++);
+  const int nkt = ntap * (a.C / BK);
   const int per = (nkt + a.splitk - 1) / a.splitk;
   const int kt0 = bz * per;
   const int kt1 = (kt0 + per < nkt) ? kt0 + per : nkt;
@@ -513,18 +556,18 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   // 128-byte lines of the gathered tensor (shifted by a pixel / a row), so a workgroup's live footprint
   // is one chunk of its pixels (+ halo) and stays in the CU's L1 / the XCD's L2 across the taps
   // (L2 misses per launch fell 3x on the 256-channel 14x14 layer, rocprofv3 TCC_MISS).
-  const int ntap = a.R * a.S;
   int is_c0 = (kt0 / ntap) * BK;
-  int is_tap = kt0 % ntap;
-  int is_r = is_tap / a.S;
-  int is_s = is_tap - is_r * a.S;
+  int is_j = kt0 % ntap;                     // index into tap_list
   auto issue = [&](int stage) {
+    const int is_tap = (int)((tap_list >> (4 * is_j)) & 15u);
+    const int is_r = is_tap / a.S, is_s = is_tap - is_r * a.S;
     int toff;
     if (a.mode == 0) toff = (is_r * a.W + is_s) * a.C;
     else if (a.stride == 1) toff = -(is_r * a.W + is_s) * a.C;
     else toff = -((is_r >> 1) * a.W + (is_s >> 1)) * a.C;
     toff += is_c0;
-    const int is_k0 = is_tap * a.C + is_c0;   // column of the [Mrows][R*S*C] weight matrix
+    const int wtap = a.tap_mask ? (int)((a.tap_w >> (4 * is_tap)) & 15u) : is_tap;
+    const int is_k0 = wtap * a.C + is_c0;   // column of the [Mrows][R*S*C] weight matrix
     const uint32_t bit = 1u << is_tap;
     char* st = smem + stage * STAGE;
 #pragma unroll
@@ -536,13 +579,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
       const int off = (b_mask[i] & bit) ? b_off[i] + toff * 2 : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + BM * RSB + (wave * BI + i) * 1024), 16, off, 0, 0, 0);
     }
-    ++is_tap;
-    if (++is_s >= a.S) {
-      is_s = 0;
-      ++is_r;
-    }
-    if (is_tap >= ntap) {
-      is_tap = is_r = is_s = 0;
+    if (++is_j >= ntap) {
+      is_j = 0;
       is_c0 += BK;
     }
   };
@@ -1418,15 +1456,17 @@ int run_igemm(ConvArgs a, hipStream_t st) {
   // the gathered dY); the 32- / 160-channel 1x1 GEMMs are the stems on im2col rows: K = 27 real taps (3x3x3,
   // iResNet / MobileFaceNet) padded to 32, K = 147 (7x7x3, resnet_std) padded to 160.
   const double alg_pos = a.mode == 1 ? (double)a.Nimg * a.H * a.W : (double)P;
-  const double alg_k = (a.mode == 0 && a.R == 1 && a.S == 1 && (a.C == 32 || a.C == 160)) ? (a.C == 32 ? 27.0 : 147.0)
-                                                                                          : (double)a.R * a.S * a.C;
+  const double alg_k = a.tap_mask ? (double)__builtin_popcount(a.tap_mask) * a.C   // parity-class launch: the taps it walks
+                       : (a.mode == 0 && a.R == 1 && a.S == 1 && (a.C == 32 || a.C == 160)) ? (a.C == 32 ? 27.0 : 147.0)
+                                                                                              : (double)a.R * a.S * a.C;
   ProfScope prof(st, 0, 2.0 * alg_pos * (double)a.Mrows * alg_k);
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
   const bool glds_ok = g_use_glds && a.C % 64 == 0 && a.R * a.S <= 9 && (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30) &&
                        (size_t)a.Mrows * a.R * a.S * a.C < (1ull << 30);
-  const bool halo_ok = (g_use_halo == 2 || (g_use_halo == 1 && a.Mrows < 128)) && glds_ok && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.splitk == 1 &&
+  const bool halo_ok = (g_use_halo == 2 || (g_use_halo == 1 && a.Mrows < 128)) && glds_ok && !a.tap_mask && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.splitk == 1 &&
                        !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.W <= 112 && a.H >= 2 && P >= 128;
+  if (a.tap_mask && !glds_ok) return fail(VLSFR_EINVAL, "conv_igemm: a parity-class launch needs the LDS-DMA kernel");
   if (halo_ok) {
     int rc;
     const bool pi2 = (128 + 2 * a.W + 2 + 7) / 8 > 32;
@@ -1486,6 +1526,10 @@ void vlsfr_profile_enable(int32_t on) { vlsfr::g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "wgrad_round_up")) {
     g_wgrad_round_up = value != 0;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "dgrad_classes")) {
+    g_dgrad_classes = value != 0;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "xcd_map")) {
@@ -1652,6 +1696,49 @@ int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT,
   a.splitk = 1;
   a.out_f32 = 0;
   a.stats = nullptr;
+  // stride 2: one launch per parity class of the input positions, each a forward-mode gather over dY with the taps that
+  // class can see (ConvArgs::cls) — 9/4 tap-positions per input position instead of 9
+  const int Hd = a.H, Wd = a.W;
+  const bool f33 = d->R == 3 && d->S == 3 && d->pad == 1, f11 = d->R == 1 && d->S == 1 && d->pad == 0;
+  if (g_dgrad_classes && g_use_glds && d->stride == 2 && (f33 || f11) && d->H == 2 * Hd && d->W == 2 * Wd && d->Cout % 64 == 0 &&
+      (size_t)d->N * Hd * Wd * d->Cout < (1ull << 30) && (size_t)d->Cin * d->R * d->S * d->Cout < (1ull << 30) &&
+      (size_t)d->N * Hd * Wd >= 128) {
+    hipStream_t st = (hipStream_t)stream;
+    a.mode = 0;
+    a.stride = 1;
+    a.Ho = Hd;
+    a.Wo = Wd;
+    a.Hf = d->H;
+    a.Wf = d->W;
+    if (f11) {   // only the even positions see dY: the rest of dX is zero
+      hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin * 2, st);
+      if (e != hipSuccess) return hip_fail(e, "vlsfr_conv2d_dgrad: memset");
+      a.tap_mask = 1u;
+      a.tap_w = 0;
+      a.cls = 1;
+      return run_igemm(a, st);
+    }
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        // virtual tap r' (row offset r' - 1 on the dY grid) <-> filter tap r:  ph = 0: r' = 1 <-> r = 1;
+        // ph = 1: r' = 1 <-> r = 2, r' = 2 <-> r = 0   (2 i - 1 + r = 2 h' + ph)
+        const int nr = ph ? 2 : 1, ns = pw ? 2 : 1;
+        const int vr[2] = {1, 2}, fr1[2] = {2, 0};
+        a.tap_mask = 0;
+        a.tap_w = 0;
+        for (int x = 0; x < nr; ++x)
+          for (int y = 0; y < ns; ++y) {
+            const int rv = vr[x], sv = vr[y];
+            const int rf = ph ? fr1[x] : 1, sf = pw ? fr1[y] : 1;
+            a.tap_mask |= 1u << (rv * 3 + sv);
+            a.tap_w |= (unsigned long long)(rf * 3 + sf) << (4 * (rv * 3 + sv));
+          }
+        a.cls = 1 + 2 * ph + pw;
+        rc = run_igemm(a, st);
+        if (rc) return rc;
+      }
+    return VLSFR_OK;
+  }
   return run_igemm(a, (hipStream_t)stream);
 }
 
