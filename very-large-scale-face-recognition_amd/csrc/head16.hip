@@ -249,7 +249,44 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void head_sweep16_kernel(Sweep16Ar
       });
       // ================= softmax: lane (r16, h) holds cos(p row 16 rb + r16, pool column tile + 16 jb + 4 h + e)
       const int64_t ct = c0 + (int64_t)t * TQ;
-      const bool plain = (word == 0u) && (ct + TQ <= c1) && !TOPK;   // wave-uniform: no masked column in this tile
+      const bool plain = (word == 0u) && (ct + TQ <= c1);   // wave-uniform: no masked column in this tile
+      if (TOPK) {
+        // hard-negative candidates of outlier rows: one comparison of the lane's best cosine of the tile against its
+        // admission threshold; the insertion (global-memory list) runs only when something qualifies — rare after the
+        // first tiles — and does not touch the softmax path below
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          if (is_out[rb]) {
+            float best = NEG_BIG;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) best = fmaxf(best, sacc[q >> 2][rb][q & 3]);
+            if (best > tk_thr[rb]) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int jl = (q >> 2) * 16 + 4 * h + (q & 3);
+                const float c = sacc[q >> 2][rb][q & 3];
+                const bool ok = plain || ((ct + jl < c1) && !((word >> jl) & 1u));
+                if (ok && c > tk_thr[rb]) {
+                  float cv = c;
+                  int ci = (int)(ct + jl);
+                  const size_t lb = list_base(rb);
+#pragma unroll
+                  for (int k = 0; k < KTOP; ++k) {
+                    const float tv = a.topk_val[lb + k];
+                    const int ti = a.topk_idx[lb + k];
+                    const bool gt = cv > tv;
+                    a.topk_val[lb + k] = gt ? cv : tv;
+                    a.topk_idx[lb + k] = gt ? ci : ti;
+                    cv = gt ? tv : cv;
+                    ci = gt ? ti : ci;
+                  }
+                  tk_thr[rb] = a.topk_val[lb + KTOP - 1];
+                }
+              }
+            }
+          }
+        }
+      }
       bf16x8 pa[RB];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
@@ -261,24 +298,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void head_sweep16_kernel(Sweep16Ar
           if (!plain) {
             const int jl = jb * 16 + 4 * h + e;
             ok = (ct + jl < c1) && !((word >> jl) & 1u);
-            if (TOPK) {
-              if (ok && is_out[rb] && c > tk_thr[rb]) {   // rare after the first tiles
-                float cv = c;
-                int ci = (int)(ct + jl);
-                const size_t lb = list_base(rb);
-#pragma unroll
-                for (int k = 0; k < KTOP; ++k) {
-                  const float tv = a.topk_val[lb + k];
-                  const int ti = a.topk_idx[lb + k];
-                  const bool gt = cv > tv;
-                  a.topk_val[lb + k] = gt ? cv : tv;
-                  a.topk_idx[lb + k] = gt ? ci : ti;
-                  cv = gt ? tv : cv;
-                  ci = gt ? ti : ci;
-                }
-                tk_thr[rb] = a.topk_val[lb + KTOP - 1];
-              }
-            }
           }
           float fac = 1.f;
           if (SV) {

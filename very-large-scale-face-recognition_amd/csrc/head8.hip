@@ -222,11 +222,47 @@ __global__ __launch_bounds__(NT, 2) void head_sweep8_kernel(Sweep16Args a) {
           __builtin_amdgcn_sched_barrier(0);
         });
         // ---- numerators of these 64 columns
-        const bool plain = ((wb0 | wb1) == 0u) && (ct + 64 * (k + 1) <= c1) && !TOPK;   // wave-uniform
+        const bool plain = ((wb0 | wb1) == 0u) && (ct + 64 * (k + 1) <= c1);   // wave-uniform
         // masked path without per-element state: the words shifted to this lane group's bits, the columns left in the chunk
         const uint32_t wq0 = wb0 >> (4 * h), wq1 = wb1 >> (4 * h);
         const int64_t left64 = c1 - ct - 64 * k - 4 * h;
         const int left = left64 > 4096 ? 4096 : (int)left64;
+        if (TOPK) {
+          // hard-negative candidates of an outlier row: the lane's best cosine of these 64 columns against its admission
+          // threshold; the insertion (global-memory list) only when something qualifies (rare after the first tiles)
+          if (is_out) {
+            float best = NEG_BIG;
+#pragma unroll
+            for (int ml = 0; ml < 4; ++ml)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) best = fmaxf(best, sacc[ml][e]);
+            if (best > tk_thr) {
+#pragma unroll
+              for (int ml = 0; ml < 4; ++ml) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float c = sacc[ml][e];
+                  const bool ok = plain || ((16 * ml + e < left) && !((((ml >> 1) ? wq1 : wq0) >> (16 * (ml & 1) + e)) & 1u));
+                  if (ok && c > tk_thr) {
+                    float cv = c;
+                    int ci = (int)(ct + 64 * k + 16 * ml + 4 * h + e);
+#pragma unroll
+                    for (int kk = 0; kk < KTOP; ++kk) {
+                      const float tv = a.topk_val[lb + kk];
+                      const int ti = a.topk_idx[lb + kk];
+                      const bool gt = cv > tv;
+                      a.topk_val[lb + kk] = gt ? cv : tv;
+                      a.topk_idx[lb + kk] = gt ? ci : ti;
+                      cv = gt ? tv : cv;
+                      ci = gt ? ti : ci;
+                    }
+                    tk_thr = a.topk_val[lb + KTOP - 1];
+                  }
+                }
+              }
+            }
+          }
+        }
         float mx = 0.f;
 #pragma unroll
         for (int ml = 0; ml < 4; ++ml) {
@@ -234,26 +270,7 @@ __global__ __launch_bounds__(NT, 2) void head_sweep8_kernel(Sweep16Args a) {
           for (int e = 0; e < 4; ++e) {
             float c = sacc[ml][e];
             bool ok = true;
-            if (!plain) {
-              ok = (16 * ml + e < left) && !((((ml >> 1) ? wq1 : wq0) >> (16 * (ml & 1) + e)) & 1u);
-              if (TOPK) {
-                if (ok && is_out && c > tk_thr) {   // rare after the first tiles
-                  float cv = c;
-                  int ci = (int)(ct + 64 * k + 16 * ml + 4 * h + e);
-#pragma unroll
-                  for (int kk = 0; kk < KTOP; ++kk) {
-                    const float tv = a.topk_val[lb + kk];
-                    const int ti = a.topk_idx[lb + kk];
-                    const bool gt = cv > tv;
-                    a.topk_val[lb + kk] = gt ? cv : tv;
-                    a.topk_idx[lb + kk] = gt ? ci : ti;
-                    cv = gt ? tv : cv;
-                    ci = gt ? ti : ci;
-                  }
-                  tk_thr = a.topk_val[lb + KTOP - 1];
-                }
-              }
-            }
+            if (!plain) ok = (16 * ml + e < left) && !((((ml >> 1) ? wq1 : wq0) >> (16 * (ml & 1) + e)) & 1u);
             float fac = 1.f;
             if (SV) {
               if (c > sv_thr) {                                   // ffc.py:122-125
