@@ -258,6 +258,12 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
 int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, float* stats, void* stream);
 int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w, void* dx, void* stream);
 int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, void* stream);
+/* The same with a workspace of vlsfr_dwconv_wgrad_workspace_bytes(d) bytes: the workgroups leave per-block partial sums
+ * there and a second kernel adds them into dw (deterministic per launch; without it every block ends in 9 C atomics on the
+ * same addresses, ~80 us per launch whatever the tensor size).  workspace NULL = vlsfr_dwconv_wgrad. */
+size_t vlsfr_dwconv_wgrad_workspace_bytes(const vlsfr_conv_desc* d);
+int vlsfr_dwconv_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 6. Normalisation / activation / layout kernels (device).  Replaces nn.BatchNorm2d in training

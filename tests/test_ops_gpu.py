@@ -249,6 +249,44 @@ def test_depthwise_conv_fwd_dgrad_wgrad(C, k, stride, pad, hw):
     close(dw.reshape(C, 1, k, k), wr.grad, 2e-3)
 
 
+@pytest.mark.parametrize("C,stride,hw,N", [(64, 1, 56, 3), (128, 1, 28, 5), (256, 1, 14, 9), (256, 1, 7, 16), (128, 2, 56, 2), (40, 1, 17, 2)])
+def test_depthwise_strip_kernels_and_partial_sum_wgrad(C, stride, hw, N):
+    """The MobileFaceNet depthwise extents (several strips per row at 56 / 28, one at 14 / 7, a ragged width): the strip
+    kernels (sliding 3 x 3 window) against the per-pixel kernels they replace (option dw_strip) and against PyTorch, and the
+    weight gradient through per-block partial sums (vlsfr_dwconv_wgrad_ws) against the one-pass atomics form."""
+    import ctypes
+    from vlsfr_amd import ops, _lib
+    torch.manual_seed(C + hw + stride)
+    x = bf(torch.randn(N, C, hw, hw))
+    w = torch.randn(C, 1, 3, 3) * 0.3
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride, 1, 1, C)
+    dy = bf(torch.randn_like(y_ref))
+    y_ref.backward(dy)
+    d = ops.ConvDesc(N, hw, hw, C, C, 3, 3, stride, 1)
+    xg, dyg = nhwc(x).cuda().to(torch.bfloat16), nhwc(dy).cuda().to(torch.bfloat16)
+    wg = w.reshape(C, 9).contiguous().cuda()
+    L = _lib.lib()
+    outs = {}
+    try:
+        for strip in (1, 0):
+            L.vlsfr_set_option(b"dw_strip", ctypes.c_int32(strip))
+            st = ops.new_sums(C, "cuda")
+            outs[strip] = (ops.dwconv_fwd(xg, wg, d, stats=st), st.sum(0), ops.dwconv_dgrad(dyg, wg, d), ops.dwconv_wgrad(dyg, xg, d),
+                           ops.dwconv_wgrad_ws(dyg, xg, d))
+    finally:
+        L.vlsfr_set_option(b"dw_strip", ctypes.c_int32(1))
+    y1, s1, dx1, dw1, dws1 = outs[1]
+    y0, s0, dx0, dw0, dws0 = outs[0]
+    close(y1, y0.cpu(), 8e-3)                                    # same products, a different summation order (one bf16 ulp)
+    close(dx1, dx0.cpu(), 8e-3)
+    close(s1, s0.cpu(), 2e-3)
+    close(y1.permute(0, 3, 1, 2), bf(y_ref.detach()), 1e-2)
+    close(dx1.permute(0, 3, 1, 2), xr.grad, 1e-2)
+    for dwv in (dw1, dws1, dw0, dws0):
+        close(dwv.reshape(C, 1, 3, 3), wr.grad, 2e-3)
+
+
 def test_stem_im2col_stride2_matches_conv():
     from vlsfr_amd import ops
     torch.manual_seed(1)

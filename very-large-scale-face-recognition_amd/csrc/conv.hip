@@ -52,6 +52,7 @@ ProfScope::~ProfScope() {
   g_prof.push_back(ProfRec{a, b, work, family});
 }
 extern int g_dw_wgrad_blocks;   // csrc/dw.hip
+extern int g_dw_strip;          // csrc/dw.hip
 int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
 
@@ -1566,6 +1567,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "wgrad_target_wgs")) {
     g_wgrad_target = value > 0 ? value : 512;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "dw_strip")) {
+    vlsfr::g_dw_strip = value != 0;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "bn_xcd")) {

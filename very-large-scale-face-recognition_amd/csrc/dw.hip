@@ -10,6 +10,7 @@
 using namespace vlsfr;
 
 namespace vlsfr {
+int g_dw_strip = 1;            // "dw_strip": 1 = strip kernels (sliding 3 x 3 window) for the stride-1 depthwise layers, 0 = per-pixel kernels
 int g_dw_wgrad_blocks = 256;   // "dw_wgrad_blocks": workgroups of the one-pass depthwise weight gradient (all add into the same 9*C addresses)
 }
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void dw3_kernel(DwArgs a) {
 // 3x3 weight gradient in one pass: per output pixel one dy load and nine predicated x loads, 72 per-thread
 // accumulators, block reduction in LDS, one atomic per (channel, tap) and block.
 template <int STRIDE>
-__global__ __launch_bounds__(256) void dw3_wgrad_kernel(const u16* dy, const u16* x, float* dw, int N, int H, int W, int C,
+__global__ __launch_bounds__(256) void dw3_wgrad_kernel(const u16* dy, const u16* x, float* dw, float* part, int N, int H, int W, int C,
                                                         int Ho, int Wo) {
   extern __shared__ float sh[];   // [9][C]
   const int cg = C / 8;
@@ -290,6 +291,241 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const u16* dy, const u16
       for (int j = 0; j < 8; ++j) atomicAdd(&sh[t * C + col * 8 + j], acc[t][j]);
   }
   __syncthreads();
+  if (part) {   // per-block partial sums, summed over the blocks by dw_wgrad_reduce_kernel (no same-address atomics)
+    for (int i = threadIdx.x; i < 9 * C; i += 256) part[(size_t)blockIdx.x * 9 * C + i] = sh[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < 9 * C; i += 256) {
+    const int t = i / C, c = i - t * C;
+    atomicAdd(&dw[(size_t)c * 9 + t], sh[i]);
+  }
+}
+
+// dw[c][t] += sum_b part[b][t][c]: one thread per (tap, channel), coalesced over the channels
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* part, int nblk, int C, float* dw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 9 * C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += part[(size_t)b * 9 * C + i];
+    s1 += part[(size_t)(b + 1) * 9 * C + i];
+    s2 += part[(size_t)(b + 2) * 9 * C + i];
+    s3 += part[(size_t)(b + 3) * 9 * C + i];
+  }
+  for (; b < nblk; ++b) s0 += part[(size_t)b * 9 * C + i];
+  const int t = i / C, c = i - t * C;
+  atomicAdd(&dw[(size_t)c * 9 + t], (s0 + s1) + (s2 + s3));   // the two backward passes of a step may share dw
+}
+
+// ---- strip kernels (3x3, pad 1, stride 1): a thread walks a run of output pixels along a row with the 3 x 3 input window
+// of its 8 channels in registers — 3 new 16-byte loads per output instead of 9 (the per-pixel form is bound by the
+// vector-memory path, not HBM: 1.1-1.9 TB/s of tensor bytes), and all index arithmetic per strip, in 32 bits.
+constexpr int DW_STRIP = 14;
+constexpr int DW_WGRAD_MAX_BLOCKS = 512;   // partial-sum slabs of the depthwise weight gradient (vlsfr_dwconv_wgrad_ws)
+
+__device__ __forceinline__ void dw_unpack(const uint4& v, float (&f)[8]) {
+  const uint32_t* w = (const uint32_t*)&v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    f[2 * j] = bf_lo(w[j]);
+    f[2 * j + 1] = bf_hi(w[j]);
+  }
+}
+
+// forward (DGRAD = false) / input gradient (true: the same stencil with the filter flipped) of a stride-1 layer
+template <bool DGRAD, bool STATS>
+__global__ __launch_bounds__(256) void dw3_strip_kernel(DwArgs a) {
+  extern __shared__ float sh[];
+  const int cg = a.C / 8;
+  const int rpb = 256 / cg;
+  const int col = threadIdx.x % cg;
+  const int rl = threadIdx.x / cg;
+  const int H = a.H, W = a.W;                      // stride 1, pad 1: input and output extents agree
+  const int nseg = (W + DW_STRIP - 1) / DW_STRIP;
+  const int nstrip = a.N * H * nseg;
+  float wr[3][3][8];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wr[r][c][j] = a.w[(size_t)(col * 8 + j) * 9 + (DGRAD ? (2 - r) * 3 + (2 - c) : r * 3 + c)];
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  if (rl < rpb) {
+    for (int sid = blockIdx.x * rpb + rl; sid < nstrip; sid += gridDim.x * rpb) {
+      const int seg = sid % nseg;
+      const int row = sid / nseg;                   // n * H + oh
+      const int oh = row % H;
+      const int ow0 = seg * DW_STRIP;
+      const int len = W - ow0 < DW_STRIP ? W - ow0 : DW_STRIP;
+      const bool rv[3] = {oh > 0, true, oh + 1 < H};
+      const u16* base = a.in + ((size_t)row * W + ow0) * a.C + col * 8;     // (n, oh, ow0)
+      u16* out = a.out + ((size_t)row * W + ow0) * a.C + col * 8;
+      const int rstep = W * a.C;
+      uint4 m1[3], c0[3], p1[3], nx[3];
+      const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const u16* rp = base + (r - 1) * rstep;
+        m1[r] = (rv[r] && ow0 > 0) ? *(const uint4*)(rp - a.C) : z;
+        c0[r] = rv[r] ? *(const uint4*)rp : z;
+        p1[r] = (rv[r] && ow0 + 1 < W) ? *(const uint4*)(rp + a.C) : z;
+      }
+      for (int i = 0; i < len; ++i) {
+        // the column after next is fetched while this output is computed (two columns of loads in flight per thread)
+        const bool cv = ow0 + i + 2 < W && i + 1 < len;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) nx[r] = (rv[r] && cv) ? *(const uint4*)(base + (r - 1) * rstep + (i + 2) * a.C) : z;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float f0[8], f1[8], f2[8];
+          dw_unpack(m1[r], f0);
+          dw_unpack(c0[r], f1);
+          dw_unpack(p1[r], f2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += f0[j] * wr[r][0][j] + f1[j] * wr[r][1][j] + f2[j] * wr[r][2][j];
+        }
+        uint4 o;
+        uint32_t* ow32 = (uint32_t*)&o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ow32[j] = pack2(acc[2 * j], acc[2 * j + 1]);
+        *(uint4*)(out + (size_t)i * a.C) = o;
+        if (STATS) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float f0 = bf_lo(ow32[j]), f1 = bf_hi(ow32[j]);
+            s[2 * j] += f0;
+            q[2 * j] += f0 * f0;
+            s[2 * j + 1] += f1;
+            q[2 * j + 1] += f1 * f1;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          m1[r] = c0[r];
+          c0[r] = p1[r];
+          p1[r] = nx[r];
+        }
+      }
+    }
+  }
+  if (STATS) {
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) sh[i] = 0.f;
+    __syncthreads();
+    if (rl < rpb) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sh[col * 8 + j], s[j]);
+        atomicAdd(&sh[a.C + col * 8 + j], q[j]);
+      }
+    }
+    __syncthreads();
+    float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
+  }
+}
+
+// weight gradient of a stride-1 layer, strip form: per output pixel one dy load and three new x loads
+__global__ __launch_bounds__(256) void dw3_wgrad_strip_kernel(const u16* dy, const u16* x, float* dw, float* part, int N, int H, int W, int C) {
+  extern __shared__ float sh[];   // [9][C]
+  const int cg = C / 8;
+  const int rpb = 256 / cg;
+  const int col = threadIdx.x % cg;
+  const int rl = threadIdx.x / cg;
+  const int nseg = (W + DW_STRIP - 1) / DW_STRIP;
+  const int nstrip = N * H * nseg;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  if (rl < rpb) {
+    for (int sid = blockIdx.x * rpb + rl; sid < nstrip; sid += gridDim.x * rpb) {
+      const int seg = sid % nseg;
+      const int row = sid / nseg;
+      const int oh = row % H;
+      const int ow0 = seg * DW_STRIP;
+      const int len = W - ow0 < DW_STRIP ? W - ow0 : DW_STRIP;
+      const bool rv[3] = {oh > 0, true, oh + 1 < H};
+      const size_t off = ((size_t)row * W + ow0) * C + col * 8;
+      const u16* base = x + off;
+      const u16* dyp = dy + off;
+      const int rstep = W * C;
+      uint4 m1[3], c0[3], p1[3], nx[3];
+      const uint4 z = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const u16* rp = base + (r - 1) * rstep;
+        m1[r] = (rv[r] && ow0 > 0) ? *(const uint4*)(rp - C) : z;
+        c0[r] = rv[r] ? *(const uint4*)rp : z;
+        p1[r] = (rv[r] && ow0 + 1 < W) ? *(const uint4*)(rp + C) : z;
+      }
+      uint4 dv = *(const uint4*)dyp, dn = z;
+      for (int i = 0; i < len; ++i) {
+        const bool cv = ow0 + i + 2 < W && i + 1 < len;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) nx[r] = (rv[r] && cv) ? *(const uint4*)(base + (r - 1) * rstep + (i + 2) * C) : z;
+        if (i + 1 < len) dn = *(const uint4*)(dyp + (size_t)(i + 1) * C);
+        float d[8];
+        dw_unpack(dv, d);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          float f0[8], f1[8], f2[8];
+          dw_unpack(m1[r], f0);
+          dw_unpack(c0[r], f1);
+          dw_unpack(p1[r], f2);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            acc[r * 3 + 0][j] += d[j] * f0[j];
+            acc[r * 3 + 1][j] += d[j] * f1[j];
+            acc[r * 3 + 2][j] += d[j] * f2[j];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          m1[r] = c0[r];
+          c0[r] = p1[r];
+          p1[r] = nx[r];
+        }
+        dv = dn;
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < 9 * C; i += 256) sh[i] = 0.f;
+  __syncthreads();
+  const bool pow2 = (cg & (cg - 1)) == 0 && cg <= 32;
+  if (pow2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = rl < rpb ? acc[t][j] : 0.f;
+        if (cg <= 32) v = lane_step_sum<32>(v);
+        if (cg <= 16) v = lane_step_sum<16>(v);
+        if (cg <= 8) v = lane_step_sum<8>(v);
+        if (cg <= 4) v = lane_step_sum<4>(v);
+        if (cg <= 2) v = lane_step_sum<2>(v);
+        if (cg <= 1) v = lane_step_sum<1>(v);
+        acc[t][j] = v;
+      }
+  }
+  if (pow2 ? (threadIdx.x & 63) < cg : rl < rpb) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&sh[t * C + col * 8 + j], acc[t][j]);
+  }
+  __syncthreads();
+  if (part) {
+    for (int i = threadIdx.x; i < 9 * C; i += 256) part[(size_t)blockIdx.x * 9 * C + i] = sh[i];
+    return;
+  }
   for (int i = threadIdx.x; i < 9 * C; i += 256) {
     const int t = i / C, c = i - t * C;
     atomicAdd(&dw[(size_t)c * 9 + t], sh[i]);
@@ -351,6 +587,18 @@ int dw_check(const vlsfr_conv_desc* d, const char* who) {
 
 inline int odim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
+// workgroups of the strip kernels: one strip (a run of up to DW_STRIP output pixels of a row) per thread and iteration
+// `cap`: the forward kernel with statistics and the weight gradient end in per-block reductions (LDS + 2 C / 9 C global
+// adds), so they run with fewer, longer-lived blocks
+int dw_strip_blocks(const vlsfr_conv_desc* d, int cap = 4096) {
+  const int rpb = 256 / (d->Cin / 8);
+  const int64_t nstrip = (int64_t)d->N * d->H * ((d->W + DW_STRIP - 1) / DW_STRIP);
+  int64_t b = (nstrip + rpb - 1) / rpb;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
 int dw_blocks(int64_t P, int C) {
   const int rpb = 256 / (C / 8);
   int64_t b = (P + (int64_t)rpb * 4 - 1) / ((int64_t)rpb * 4);
@@ -374,7 +622,11 @@ int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, vo
   const size_t shb = stats ? 2 * a.C * sizeof(float) : 0;
   hipStream_t st = (hipStream_t)stream;
   if (d->R == 3 && d->pad == 1) {
-    if (d->stride == 1) {
+    if (d->stride == 1 && vlsfr::g_dw_strip) {
+      const dim3 sgrid(dw_strip_blocks(d, stats ? 512 : 4096));
+      if (stats) hipLaunchKernelGGL((dw3_strip_kernel<false, true>), sgrid, block, shb, st, a);
+      else hipLaunchKernelGGL((dw3_strip_kernel<false, false>), sgrid, block, shb, st, a);
+    } else if (d->stride == 1) {
       if (stats) hipLaunchKernelGGL((dw3_kernel<1, false, true>), grid, block, shb, st, a);
       else hipLaunchKernelGGL((dw3_kernel<1, false, false>), grid, block, shb, st, a);
     } else {
@@ -397,7 +649,9 @@ int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w,
   const int64_t P = (int64_t)a.N * a.H * a.W;
   const dim3 grid(dw_blocks(P, a.C)), block(256);
   if (d->R == 3 && d->pad == 1) {
-    if (d->stride == 1) hipLaunchKernelGGL((dw3_kernel<1, true, false>), grid, block, 0, (hipStream_t)stream, a);
+    if (d->stride == 1 && vlsfr::g_dw_strip)
+      hipLaunchKernelGGL((dw3_strip_kernel<true, false>), dim3(dw_strip_blocks(d)), block, 0, (hipStream_t)stream, a);
+    else if (d->stride == 1) hipLaunchKernelGGL((dw3_kernel<1, true, false>), grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dw3_kernel<2, true, false>), grid, block, 0, (hipStream_t)stream, a);
   } else {
     hipLaunchKernelGGL(dw_conv_kernel, grid, block, 0, (hipStream_t)stream, a);
@@ -407,6 +661,16 @@ int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w,
 }
 
 int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, void* stream) {
+  return vlsfr_dwconv_wgrad_ws(d, dy, x, dw, nullptr, 0, stream);
+}
+
+size_t vlsfr_dwconv_wgrad_workspace_bytes(const vlsfr_conv_desc* d) {
+  if (dw_check(d, "vlsfr_dwconv_wgrad_workspace_bytes") || d->R != 3 || d->pad != 1) return 0;
+  return (size_t)DW_WGRAD_MAX_BLOCKS * 9 * d->Cin * sizeof(float);
+}
+
+int vlsfr_dwconv_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   int rc = dw_check(d, "vlsfr_dwconv_wgrad");
   if (rc) return rc;
   if (!dy || !x || !dw) return fail(VLSFR_EINVAL, "vlsfr_dwconv_wgrad: null buffer");
@@ -414,15 +678,30 @@ int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
   const int64_t P = (int64_t)d->N * Ho * Wo;
   int nb = dw_blocks(P, d->Cin);
   if (d->R == 3 && d->pad == 1) {
-    if (nb > vlsfr::g_dw_wgrad_blocks) nb = vlsfr::g_dw_wgrad_blocks;
+    hipStream_t st = (hipStream_t)stream;
+    const bool strip = d->stride == 1 && vlsfr::g_dw_strip;
+    if (strip) nb = dw_strip_blocks(d, DW_WGRAD_MAX_BLOCKS);
+    // with a workspace the blocks leave partial sums and a second kernel adds them up: the one-pass form ends in
+    // 9 C atomics per block on the same 9 C addresses, which alone costs ~80 us per launch
+    const int cap = workspace ? DW_WGRAD_MAX_BLOCKS : vlsfr::g_dw_wgrad_blocks;
+    if (nb > cap) nb = cap;
+    float* part = (workspace && workspace_bytes >= (size_t)nb * 9 * d->Cin * sizeof(float)) ? (float*)workspace : nullptr;
+    if (!part && nb > vlsfr::g_dw_wgrad_blocks) nb = vlsfr::g_dw_wgrad_blocks;
     const size_t shb = 9 * d->Cin * sizeof(float);
-    if (d->stride == 1)
-      hipLaunchKernelGGL((dw3_wgrad_kernel<1>), dim3(nb), dim3(256), shb, (hipStream_t)stream, (const u16*)dy, (const u16*)x, dw,
-                         d->N, d->H, d->W, d->Cin, Ho, Wo);
+    if (strip)
+      hipLaunchKernelGGL(dw3_wgrad_strip_kernel, dim3(nb), dim3(256), shb, st, (const u16*)dy, (const u16*)x, dw, part, d->N, d->H, d->W,
+                         d->Cin);
+    else if (d->stride == 1)
+      hipLaunchKernelGGL((dw3_wgrad_kernel<1>), dim3(nb), dim3(256), shb, st, (const u16*)dy, (const u16*)x, dw, part, d->N, d->H, d->W,
+                         d->Cin, Ho, Wo);
     else
-      hipLaunchKernelGGL((dw3_wgrad_kernel<2>), dim3(nb), dim3(256), shb, (hipStream_t)stream, (const u16*)dy, (const u16*)x, dw,
-                         d->N, d->H, d->W, d->Cin, Ho, Wo);
+      hipLaunchKernelGGL((dw3_wgrad_kernel<2>), dim3(nb), dim3(256), shb, st, (const u16*)dy, (const u16*)x, dw, part, d->N, d->H, d->W,
+                         d->Cin, Ho, Wo);
     VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad");
+    if (part) {
+      hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((9 * d->Cin + 255) / 256), dim3(256), 0, st, part, nb, d->Cin, dw);
+      VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad reduce");
+    }
     return VLSFR_OK;
   }
   if (nb > 512) nb = 512;

@@ -157,11 +157,11 @@ int build(vlsfr_mobilenet* n) {
   n->off_invnorm = n->take_ctx((size_t)n->B * 4);
   // scratch: per-unit output gradients are needed until their producers have run (residual fan-out),
   // so keep one gradient buffer per "live" tensor: 4 rotating buffers + small fp32 areas
-  for (const auto& u : n->units)
-    if (u.kind != DW) {
-      const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&u.d, 0);   // split-K slabs (vlsfr_conv2d_wgrad_ws)
-      if (w > n->wgrad_ws) n->wgrad_ws = w;
-    }
+  for (const auto& u : n->units) {
+    // split-K slabs (vlsfr_conv2d_wgrad_ws) / per-block partial sums of the depthwise weight gradient (vlsfr_dwconv_wgrad_ws)
+    const size_t w = u.kind != DW ? vlsfr_conv2d_wgrad_workspace_bytes(&u.d, 0) : vlsfr_dwconv_wgrad_workspace_bytes(&u.d);
+    if (w > n->wgrad_ws) n->wgrad_ws = w;
+  }
   {
     const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&n->l1d, 0);
     if (w > n->wgrad_ws) n->wgrad_ws = w;
@@ -338,7 +338,7 @@ int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const 
       RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, in, grads[u.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_conv2d_dgrad(&u.d, dc, wc + u.off_wT, din, st));
     } else {
-      RUN(vlsfr_dwconv_wgrad(&u.d, dc, in, grads[u.p_w], st));
+      RUN(vlsfr_dwconv_wgrad_ws(&u.d, dc, in, grads[u.p_w], sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_dwconv_dgrad(&u.d, dc, params[u.p_w], din, st));
     }
     cur = t2;

@@ -129,6 +129,18 @@ def dwconv_wgrad(dy, x, desc, dw=None):
     return dw
 
 
+def dwconv_wgrad_ws(dy, x, desc, dw=None):
+    """The depthwise weight gradient through per-block partial sums in a workspace (vlsfr_dwconv_wgrad_ws)."""
+    if dw is None:
+        dw = torch.zeros(desc.Cout, desc.R * desc.S, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    L.vlsfr_dwconv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    n = int(L.vlsfr_dwconv_wgrad_workspace_bytes(ctypes.byref(desc)))
+    ws = torch.empty(max(n, 16), dtype=torch.uint8, device=x.device)
+    _call("vlsfr_dwconv_wgrad_ws", ctypes.byref(desc), _p(dy), _p(x), _p(dw), _p(ws), ctypes.c_size_t(n), _st())
+    return dw
+
+
 def embed_fwd(fc, fc_bias, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     B, D = fc.shape
     mk = lambda *s: torch.empty(*s, dtype=torch.float32, device=fc.device)
