@@ -29,3 +29,12 @@ for C, h, s, cnt in SHAPES:
     print("C=%3d %2dx%2d s%d x%d | fwd %6.1f us %5.2f TB/s | dgrad %6.1f us %5.2f TB/s | wgrad %6.1f us %5.2f TB/s | %.2f ms/step" %
           (C, h, h, s, cnt, tf * 1e6, (bi + bo) / tf / 1e12, td * 1e6, (bi + bo) / td / 1e12, tw * 1e6, (bi + bo) / tw / 1e12, ms), flush=True)
 print("depthwise kernels per step: %.1f ms" % tot)
+# the 7x7 valid "linear7" layer (mobilefacenet_def.py:88): [B, 7, 7, 512] -> [B, 1, 1, 512]
+d = ops.ConvDesc(B, 7, 7, 512, 512, 7, 7, 1, 0)
+x = torch.randn(B, 7, 7, 512, device="cuda").to(torch.bfloat16)
+w = torch.randn(512, 49, device="cuda") * 0.1
+dy = torch.randn(B, 1, 1, 512, device="cuda").to(torch.bfloat16)
+dw = torch.zeros(512, 49, device="cuda")
+st = ops.new_sums(512, "cuda")
+tf = timeit(lambda: ops.dwconv_fwd(x, w, d, stats=st)); td = timeit(lambda: ops.dwconv_dgrad(dy, w, d)); tw = timeit(lambda: ops.dwconv_wgrad(dy, x, d, dw))
+print("linear7 512 7x7 valid | fwd %6.1f us | dgrad %6.1f us | wgrad %6.1f us | %.2f ms/step" % (tf * 1e6, td * 1e6, tw * 1e6, (4 * tf + 2 * td + 2 * tw) * 1e3))

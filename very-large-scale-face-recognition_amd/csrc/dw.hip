@@ -119,6 +119,49 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
   }
 }
 
+// "Global" depthwise forward (MobileFaceNet linear7, mobilefacenet_def.py:88: k x k valid filter on a k x k map, one output
+// pixel per image): one workgroup per image, the k*k taps dealt to four thread groups of C / 8 lanes, combined through LDS.
+// The generic kernel has one thread per (output pixel, 8 channels) — 16 workgroups for a batch of 256 (185 us per launch).
+__global__ __launch_bounds__(256) void dw_global_fwd_kernel(DwArgs a) {
+  extern __shared__ float sh[];                 // [4][C] partial outputs, then [2][C] statistics
+  const int cg = a.C / 8;                       // <= 64 (host-checked)
+  const int col = threadIdx.x % cg, grp = threadIdx.x / cg;
+  const int ngrp = 256 / cg;                    // >= 4
+  const int n = blockIdx.x;
+  const int taps = a.k * a.k;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (grp < 4) {
+    const u16* in = a.in + (size_t)n * taps * a.C + col * 8;
+    for (int t = grp; t < taps; t += 4) {
+      const uint4 v = *(const uint4*)(in + (size_t)t * a.C);
+      const uint32_t* vw = (const uint32_t*)&v;
+      const float* wp = a.w + (size_t)(col * 8) * taps + t;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += bf_lo(vw[j]) * wp[(2 * j) * taps];
+        acc[2 * j + 1] += bf_hi(vw[j]) * wp[(2 * j + 1) * taps];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[grp * a.C + col * 8 + j] = acc[j];
+  }
+  (void)ngrp;
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    const float y = (sh[c] + sh[a.C + c]) + (sh[2 * a.C + c] + sh[3 * a.C + c]);
+    const __bf16 yb = (__bf16)y;
+    a.out[(size_t)n * a.C + c] = __builtin_bit_cast(u16, yb);
+    if (a.stats) {
+      const float f = (float)yb;
+      float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+      atomicAdd(&dst[c], f);
+      atomicAdd(&dst[a.C + c], f * f);
+    }
+  }
+}
+
 // 3x3 / pad 1 specialisation (every depthwise layer of MobileFaceNet but the 7x7 global one): the 72
 // weights of the thread's 8 channels live in registers, the nine taps of a pixel are nine predicated
 // 16-byte loads issued together (no per-tap branches, no weight loads in the loop); stride and
@@ -633,6 +676,8 @@ int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, vo
       if (stats) hipLaunchKernelGGL((dw3_kernel<2, false, true>), grid, block, shb, st, a);
       else hipLaunchKernelGGL((dw3_kernel<2, false, false>), grid, block, shb, st, a);
     }
+  } else if (a.Ho == 1 && a.Wo == 1 && d->pad == 0 && d->R == d->H && d->S == d->W && a.C <= 512 && a.C % 8 == 0 && 256 / (a.C / 8) >= 4) {
+    hipLaunchKernelGGL(dw_global_fwd_kernel, dim3(a.N), block, 4 * a.C * sizeof(float), st, a);
   } else {
     hipLaunchKernelGGL(dw_conv_kernel, grid, block, shb, st, a);
   }
