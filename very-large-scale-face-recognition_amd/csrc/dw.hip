@@ -344,21 +344,26 @@ __global__ __launch_bounds__(256) void dw3_wgrad_kernel(const u16* dy, const u16
   }
 }
 
-// dw[c][t] += sum_b part[b][t][c]: one thread per (tap, channel), coalesced over the channels
+// dw[c][t] += sum_b part[b][t][c]: one thread per (tap, channel) and slice of the blocks (blockIdx.y of DW_REDUCE_SLICES:
+// a single thread walking 512 partials is 500 dependent-latency loads), coalesced over the channels
+constexpr int DW_REDUCE_SLICES = 8;
 __global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* part, int nblk, int C, float* dw) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 9 * C) return;
+  const int per = (nblk + DW_REDUCE_SLICES - 1) / DW_REDUCE_SLICES;
+  const int b0 = blockIdx.y * per, b1 = b0 + per < nblk ? b0 + per : nblk;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
+  int b = b0;
+  for (; b + 3 < b1; b += 4) {
     s0 += part[(size_t)b * 9 * C + i];
     s1 += part[(size_t)(b + 1) * 9 * C + i];
     s2 += part[(size_t)(b + 2) * 9 * C + i];
     s3 += part[(size_t)(b + 3) * 9 * C + i];
   }
-  for (; b < nblk; ++b) s0 += part[(size_t)b * 9 * C + i];
+  for (; b < b1; ++b) s0 += part[(size_t)b * 9 * C + i];
+  if (b1 <= b0) return;
   const int t = i / C, c = i - t * C;
-  atomicAdd(&dw[(size_t)c * 9 + t], (s0 + s1) + (s2 + s3));   // the two backward passes of a step may share dw
+  atomicAdd(&dw[(size_t)c * 9 + t], (s0 + s1) + (s2 + s3));   // 8 slices + the two backward passes of a step share dw
 }
 
 // ---- strip kernels (3x3, pad 1, stride 1): a thread walks a run of output pixels along a row with the 3 x 3 input window
@@ -744,7 +749,7 @@ int vlsfr_dwconv_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
                          d->Cin, Ho, Wo);
     VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad");
     if (part) {
-      hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((9 * d->Cin + 255) / 256), dim3(256), 0, st, part, nb, d->Cin, dw);
+      hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((9 * d->Cin + 255) / 256, DW_REDUCE_SLICES), dim3(256), 0, st, part, nb, d->Cin, dw);
       VLSFR_HIP_CHECK_LAUNCH("vlsfr_dwconv_wgrad reduce");
     }
     return VLSFR_OK;
