@@ -146,8 +146,25 @@ def cpu_baseline(args):
     return out
 
 
+_RESULT_FD = None
+
+
+def emit(line):
+    """The one JSON line of the contract, on the process's ORIGINAL stdout."""
+    if _RESULT_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_RESULT_FD, (line + "\n").encode())
+
+
 def main():
+    global _RESULT_FD
     args = parse()
+    # stdout carries exactly one line (rank 0's JSON): libraries that print to fd 1 on their own — RCCL's version banner at
+    # communicator creation, gloo's connection notes — go to stderr with everything else
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     _skip = os.environ.get("BENCH_SKIP", "").split(",")      # diagnostic A/B switches
     if "threads" not in _skip:
         torch.set_num_threads(host_threads())
@@ -316,8 +333,8 @@ def main():
 
     if args.counters_only:   # rocprofv3 --pmc passes: the K timed steps are all that is wanted (no HIP events anywhere)
         if rank == 0:
-            print(json.dumps({"value": round(world * 2 * B * args.steps / dt, 2), "unit": "faces/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
-                              "note": "--counters-only run: no roofline legs"}), flush=True)
+            emit(json.dumps({"value": round(world * 2 * B * args.steps / dt, 2), "unit": "faces/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                             "note": "--counters-only run: no roofline legs"}))
         return
     L.vlsfr_profile_event_overhead_us.restype = ctypes.c_double
     ev_us = float(L.vlsfr_profile_event_overhead_us(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
@@ -412,7 +429,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(out))
+    emit(json.dumps(out))
 
 
 if __name__ == "__main__":

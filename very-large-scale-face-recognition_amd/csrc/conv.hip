@@ -72,6 +72,7 @@ int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace s
 int g_wgrad_round_up = 0;    // "wgrad_round_up": 1 = round the slice count up (may exceed wgrad_target_wgs), the round-1 rule
 int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
+int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
@@ -1476,7 +1477,9 @@ int run_igemm(ConvArgs a, hipStream_t st) {
     if (rc != VLSFR_OK) return rc;
   } else if (glds_ok) {
     int rc;
-    const bool big = a.Mrows >= 128;
+    // 128 x 128 tiles unless that leaves fewer workgroups than g_small_tile_wgs (small batches: the 256-channel 14 x 14
+    // layers of batch 64 make 196 tiles for 256 CUs): then 64 x 128 tiles, twice as many
+    const bool big = a.Mrows >= 128 && wg_big >= g_small_tile_wgs;
     if (g_use_glds == 1) rc = big ? launch_igemm_glds<128, 128, 64, 4>(a, P, st) : launch_igemm_glds<64, 128, 64, 4>(a, P, st);
     else if (g_use_glds == 2) rc = big ? launch_igemm_glds<128, 128, 32, 4>(a, P, st) : launch_igemm_glds<64, 128, 32, 4>(a, P, st);
     else if (g_use_glds == 5)   // 8-wave tiles, 3-stage ring, one workgroup per CU
@@ -1527,6 +1530,10 @@ void vlsfr_profile_enable(int32_t on) { vlsfr::g_prof_on = on != 0; }
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "wgrad_round_up")) {
     g_wgrad_round_up = value != 0;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "small_tile_wgs")) {
+    g_small_tile_wgs = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "dgrad_classes")) {
