@@ -206,3 +206,24 @@ def test_two_rank_training_driver_checkpoints_shard_wise_and_resumes(tmp_path):
         assert float(np.abs(a["shard"] - b["shard"]).max()) < 0.05
         assert rel(b["w"], a["w"]) < 2e-2
     assert rel(res[1]["a"]["w"], res[0]["a"]["w"]) < 1e-6
+
+
+def test_bench_multi_gpu_code_path_over_rccl_with_one_rank():
+    """bench.py --force-dist: process group on the nccl (= RCCL) backend, stream pool warmed before it, shard-local pool,
+    every collective of the sharded head and of the partitioned SGD through RCCL, per-stage events — with the one rank a
+    1-GPU box has.  stdout must carry exactly the one JSON line of the contract."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--net", "irtiny", "--feat", "512", "--identities", "8192",
+                        "--batch", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    assert out["config"]["parallelism"] == "dp1+zero1-sgd+pool-sharded" and out["n_gpus"] == 1
+    assert out["value"] > 0 and np.isfinite(out["config"]["loss"])
+    assert out["roofline"]["achieved"] > 0
