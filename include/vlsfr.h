@@ -294,6 +294,16 @@ int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       const float* slope, float* red, const void* dx_add, float* dgamma, float* dbeta,
                       float* dslope, int32_t dy_nchw, void* stream);
+/* The same, chained with the BatchNorm backward that consumes dx as ITS dY (iResNet: bn1 of block k writes the output gradient
+ * of block k - 1, whose bn3 is next in the chain): with next_x (that layer's input, same shape as dx; a plain BatchNorm)
+ * the apply kernel also accumulates that layer's reduction into next_red ([VLSFR_BN_REPL][3][C], zeroed) from the rounded
+ * dx; the later call for that layer passes red_ready = 1 and skips its own reduction kernel — one tensor read instead of
+ * two, one launch less per block. */
+int vlsfr_bn_backward_chain(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
+                            const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw,
+                            int32_t red_ready, const void* next_x, const float* next_mean, const float* next_invstd,
+                            float* next_red, void* stream);
 int vlsfr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* e = normalize(bn1d(fc + fc_bias)); all fp32 [B, D] */
 int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, const float* beta,

@@ -53,6 +53,7 @@ ProfScope::~ProfScope() {
 }
 extern int g_dw_wgrad_blocks;   // csrc/dw.hip
 extern int g_dw_strip;          // csrc/dw.hip
+extern int g_bn_chain;          // csrc/iresnet.cpp
 int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
 
@@ -1574,6 +1575,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "wgrad_target_wgs")) {
     g_wgrad_target = value > 0 ? value : 512;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "bn_chain")) {
+    vlsfr::g_bn_chain = value != 0;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "dw_strip")) {

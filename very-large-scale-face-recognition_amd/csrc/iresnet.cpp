@@ -14,6 +14,11 @@
 
 #include "common_host.h"
 
+namespace vlsfr {
+int g_bn_chain = 1;   // "bn_chain": bn1 backward of block k accumulates the reduction of bn3 of block k - 1 (vlsfr_bn_backward_chain)
+}
+using vlsfr::g_bn_chain;
+
 namespace {
 
 constexpr float BN_EPS = 1e-5f;
@@ -277,12 +282,18 @@ int bn_forward(const Bn& b, const void* x, void* y, int64_t M, int HW, const voi
                         (float*)(ctx + b.off_invstd), rm, rv, BN_EPS, BN_MOM, out_sums, out_nchw, st);
 }
 
+// red_ready: this layer's reduction was accumulated by the call that produced dy (its `next`); next / next_x: the
+// BatchNorm whose dY is this call's dx, and that layer's input (vlsfr_bn_backward_chain)
 int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M, int HW, const void* dx_add,
-                int dy_nchw, const float* const* params, float* const* grads, char* ctx, void* st) {
-  return vlsfr_bn_backward(dy, x, dx, M, b.C, HW, (const float*)(ctx + b.off_mean), (const float*)(ctx + b.off_invstd),
-                           params[b.p_w], params[b.p_b], b.p_slope >= 0 ? params[b.p_slope] : nullptr,
-                           (float*)(ctx + b.off_red), dx_add, grads[b.p_w], grads[b.p_b],
-                           b.p_slope >= 0 ? grads[b.p_slope] : nullptr, dy_nchw, st);
+                int dy_nchw, const float* const* params, float* const* grads, char* ctx, void* st, int red_ready = 0,
+                const Bn* next = nullptr, const void* next_x = nullptr) {
+  return vlsfr_bn_backward_chain(dy, x, dx, M, b.C, HW, (const float*)(ctx + b.off_mean), (const float*)(ctx + b.off_invstd),
+                                 params[b.p_w], params[b.p_b], b.p_slope >= 0 ? params[b.p_slope] : nullptr,
+                                 (float*)(ctx + b.off_red), dx_add, grads[b.p_w], grads[b.p_b],
+                                 b.p_slope >= 0 ? grads[b.p_slope] : nullptr, dy_nchw, red_ready, next ? next_x : nullptr,
+                                 next ? (const float*)(ctx + next->off_mean) : nullptr,
+                                 next ? (const float*)(ctx + next->off_invstd) : nullptr,
+                                 next ? (float*)(ctx + next->off_red) : nullptr, st);
 }
 
 }  // namespace
@@ -431,6 +442,7 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   // blocks in reverse; dcur rotates through the three gradient buffers
   int cur_i = 1;
   int stage = 4, left = n->layers[3];   // blocks of the current stage still to go
+  bool chained = false;                 // bn3 of the current block already has its reduction
   for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
     const Block& b = n->blocks[k];
     const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
@@ -438,8 +450,8 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
     char* t1 = sc.g[(cur_i + 1) % 3];
     char* t2 = sc.g[(cur_i + 2) % 3];
     const char* dout = sc.g[cur_i];
-    // main branch
-    RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
+    // main branch (the reduction of bn3 came with the kernel that wrote dout: bn1 of block k + 1, below)
+    RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st, chained ? 1 : 0));
     RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
     RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
     RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st));   // d c1
@@ -452,8 +464,11 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
       RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
       add = sc.idn;
     }
-    // d x_in = bn1 backward of d a1, plus the shortcut gradient
-    RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st));
+    // d x_in = bn1 backward of d a1, plus the shortcut gradient; x_in is the output of block k - 1, so this IS the dY of
+    // that block's bn3: its reduction is accumulated here (one read of c2 instead of a kernel reading dout and c2)
+    chained = g_bn_chain && k > 0;
+    RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st, 0, chained ? &n->blocks[k - 1].bn3 : nullptr,
+                    chained ? ctx + n->blocks[k - 1].c2 : nullptr));
     cur_i = (cur_i + 1) % 3;   // t1 is the new dcur
     if (--left == 0 && stage > 1) {   // stage 4, 3, 2 complete -> buckets 1, 2, 3 (stage 1 goes with the stem)
       RUN(signal(5 - stage));

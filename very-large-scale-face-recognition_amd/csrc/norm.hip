@@ -303,6 +303,13 @@ struct BnBwdArgs {
   float* dslope;
   int dy_nchw;            // dy laid out as the flatten order (see bn_apply out_nchw)
   int xcd;                // 1: block -> row range in XCD-major order (bn_block_id)
+  // apply kernel, FLAGS & 8: dx IS the dY of a following BatchNorm backward (same shape, no PReLU) whose input is nx — its
+  // reduction (sum dY, sum dY * xhat) is accumulated here from the rounded dx and one extra read of nx, instead of a
+  // separate kernel reading both tensors again
+  const u16* nx;
+  const float* n_mean;
+  const float* n_invstd;
+  float* n_red;           // [REPL][3][C], pre-zeroed
 };
 
 __device__ __forceinline__ float load_dy_nchw(const BnBwdArgs& a, int64_t r, int c) {
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
 
 template <int FLAGS>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
-  constexpr bool PRELU = FLAGS & 1, NCHW = FLAGS & 2, DXADD = FLAGS & 4;
+  constexpr bool PRELU = FLAGS & 1, NCHW = FLAGS & 2, DXADD = FLAGS & 4, NEXT = FLAGS & 8;
   extern __shared__ float sh[];   // k0[C] = gamma*invstd, k1[C] = mean dz, k2[C] = mean dz*xhat
   const int C = a.C;
   const int tid = threadIdx.x;
@@ -404,7 +411,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   }
   __syncthreads();
   const RowMap m = row_map(C);
-  if (!m.active) return;
+  if (!NEXT && !m.active) return;
+  float nv[3][8];   // NEXT: sum dx, sum dx * nx (raw), unused
+#pragma unroll
+  for (int j = 0; j < 8; ++j) nv[0][j] = nv[1][j] = nv[2][j] = 0.f;
+  if (m.active) {
   // dx = k0*(dz - k1 - xhat*k2) = A*dz + Bx*x + Cc with xhat = x*invstd - mean*invstd folded in;
   // dz = dy * (z <= 0 ? slope : 1): As = A*slope
   float A[8], As[8], Bx[8], Cc[8], zs[8], zo[8];
@@ -433,15 +444,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const u16* x0 = a.x + r0 * C + m.col * 8;
   const u16* d0 = a.dy + r0 * C + m.col * 8;
   const u16* q0 = DXADD ? a.dx_add + r0 * C + m.col * 8 : nullptr;
+  const u16* n0 = NEXT ? a.nx + r0 * C + m.col * 8 : nullptr;
   u16* o0 = a.dx + r0 * C + m.col * 8;
   for (int rl = m.rl; rl < nrow; rl += UF * m.rpb) {
-    bf8 xv[UF], dv[UF], av[UF];
+    bf8 xv[UF], dv[UF], av[UF], nxv[UF];
 #pragma unroll
     for (int u = 0; u < UF; ++u)
       if (rl + u * m.rpb < nrow) {
         xv[u].raw = *(const uint4*)(x0 + (rl + u * m.rpb) * C);
         if (!NCHW) dv[u].raw = *(const uint4*)(d0 + (rl + u * m.rpb) * C);
         if (DXADD) av[u].raw = *(const uint4*)(q0 + (rl + u * m.rpb) * C);
+        if (NEXT) nxv[u].raw = *(const uint4*)(n0 + (rl + u * m.rpb) * C);
       }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
@@ -457,8 +470,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         if (DXADD) d += av[u].get(j);
         o[j] = d;
       }
-      *(uint4*)(o0 + (rl + u * m.rpb) * C) = pack8(o);
+      bf8 ov;
+      ov.raw = pack8(o);
+      *(uint4*)(o0 + (rl + u * m.rpb) * C) = ov.raw;
+      if (NEXT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dz = ov.get(j);            // the value the following BatchNorm reads back
+          nv[0][j] += dz;
+          nv[1][j] += dz * nxv[u].get(j);
+        }
+      }
     }
+  }
+  }   // m.active
+  if (NEXT) {
+    float c_is2[8], c_mean2[8];
+    load8(a.n_invstd, m.col * 8, 1.f, c_is2);
+    load8(a.n_mean, m.col * 8, 0.f, c_mean2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nv[1][j] = c_is2[j] * (nv[1][j] - c_mean2[j] * nv[0][j]);
+    __syncthreads();   // sh (k0, k1, k2) has been consumed by every thread
+    block_reduce_to_replica<3>(nv, m, C, sh, a.n_red);
   }
 }
 
@@ -784,27 +817,42 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
 int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW, const float* mean,
                       const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
                       const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw, void* stream) {
+  return vlsfr_bn_backward_chain(dy, x, dx, M, C, HW, mean, invstd, gamma, beta, slope, red, dx_add, dgamma, dbeta, dslope, dy_nchw, 0,
+                                 nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+int vlsfr_bn_backward_chain(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW, const float* mean,
+                            const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
+                            const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw, int32_t red_ready,
+                            const void* next_x, const float* next_mean, const float* next_invstd, float* next_red, void* stream) {
   if (!dy || !x || !dx || !mean || !invstd || !red || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_backward: bad argument");
+  if (next_x && (!next_mean || !next_invstd || !next_red))
+    return fail(VLSFR_EINVAL, "vlsfr_bn_backward_chain: next_x needs next_mean, next_invstd and next_red");
   hipStream_t st = (hipStream_t)stream;
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
-              (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw, g_bn_xcd && nblk >= 16};
+              (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw, g_bn_xcd && nblk >= 16,
+              (const u16*)next_x, next_mean, next_invstd, next_red};
   const int rflags = (slope ? 1 : 0) | (dy_nchw ? 2 : 0);
-  const int aflags = rflags | (dx_add ? 4 : 0);
+  const int aflags = rflags | (dx_add ? 4 : 0) | (next_x ? 8 : 0);
   const dim3 grid(nblk), block(256);
   const size_t shb = 3 * C * sizeof(float);
-  switch (rflags) {
-    case 0: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, shb, st, a); break;
-    case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, shb, st, a); break;
-    case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, block, shb, st, a); break;
-    default: hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, grid, block, shb, st, a); break;
+  if (!red_ready) {   // red_ready: the producer of dy accumulated this layer's reduction already (next_* of its call)
+    switch (rflags) {
+      case 0: hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, shb, st, a); break;
+      case 1: hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, shb, st, a); break;
+      case 2: hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, grid, block, shb, st, a); break;
+      default: hipLaunchKernelGGL(bn_bwd_reduce_kernel<3>, grid, block, shb, st, a); break;
+    }
+    VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward reduce");
   }
-  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward reduce");
 #define VLSFR_CASE(F) case F: hipLaunchKernelGGL(bn_bwd_apply_kernel<F>, grid, block, shb, st, a); break;
   switch (aflags) {
     VLSFR_CASE(0) VLSFR_CASE(1) VLSFR_CASE(2) VLSFR_CASE(3) VLSFR_CASE(4) VLSFR_CASE(5) VLSFR_CASE(6) VLSFR_CASE(7)
+    VLSFR_CASE(8) VLSFR_CASE(12)          // the chain form: plain BatchNorm, with / without the identity-branch gradient
+    default: return fail(VLSFR_EINVAL, "vlsfr_bn_backward_chain: next_x goes with a plain BatchNorm (no PReLU, NHWC dy)");
   }
 #undef VLSFR_CASE
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward apply");
