@@ -166,7 +166,7 @@ class DcpHead(object):
                        self.shadow.ptr(not self.precise, "fp8") if fp8 else None)
 
     def _workspace(self, cfg, device):
-        key = (cfg.B, cfg.n_rows_total, str(device), cfg.pool_bf16, cfg.pool_fp8, cfg.precise, cfg.loss_type, cfg.scale)
+        key = (cfg.B, cfg.n_rows_total, str(device), cfg.pool_bf16, cfg.pool_fp8, cfg.precise, cfg.loss_type, cfg.scale, cfg.n_chunks)
         if self._ws_key != key:
             self.L.vlsfr_head_workspace_bytes.restype = ctypes.c_size_t
             self.L.vlsfr_head_workspace_bytes.argtypes = [ctypes.POINTER(HeadCfg)]
