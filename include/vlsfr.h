@@ -386,6 +386,17 @@ int vlsfr_iresnet_backward_overlap(const vlsfr_iresnet* n, const float* demb, co
                                    float* const* grads, const void* wcache, void* ctx, void* scratch, void* ring,
                                    size_t ring_bytes, void* const* stage_events, void* side_stream,
                                    void* const* events, void* stream);
+/* Teacher-forced execution of IBasicBlocks k0 .. k1 - 1 (resnet_arcface.py:44-55) for parity tests of the executor's wiring:
+ * the same kernels and context slots as vlsfr_iresnet_forward / _backward, but from an activation x_in (bf16 NHWC, the
+ * tensor block k0 reads: [B, H, H, cin]) and an output gradient dout (bf16 NHWC [B, Ho, Ho, planes] of block k1 - 1)
+ * supplied by the caller.  out / dx: the range's output and input gradient (bf16 NHWC); parameter gradients are
+ * accumulated (+=) into grads as in the full pass.  vlsfr_iresnet_block_info: info = {cin, planes, H, Ho, stride,
+ * has_downsample, index of bn1.weight in the parameter table, number of blocks}. */
+int vlsfr_iresnet_block_info(const vlsfr_iresnet* n, int32_t k, int32_t* info /*[8]*/);
+int vlsfr_iresnet_forward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1, const void* x_in, const float* const* params,
+                                 float* const* running, const void* wcache, void* ctx, void* scratch, void* out, void* stream);
+int vlsfr_iresnet_backward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1, const void* dout, const float* const* params,
+                                  float* const* grads, const void* wcache, void* ctx, void* scratch, void* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7b. MobileFaceNet backbone executor: same contract as section 7 for reference
@@ -408,6 +419,16 @@ int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const
                             void* stream);
 int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const float* const* params,
                              float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
+/* Teacher-forced execution of units u0 .. u1 - 1, u0 >= 1 (a unit = conv -> BN [-> PReLU] [+ residual]; a BottleNeck,
+ * mobilefacenet_def.py:27-52, is three consecutive units), as vlsfr_iresnet_forward_blocks: x_in = output of unit u0 - 1,
+ * dout = gradient of the output of unit u1 - 1, both bf16 NHWC.  vlsfr_mobilenet_unit_info: info = {kind (0 stem,
+ * 1 pointwise, 2 depthwise), Cin, Cout, H, Ho, residual source unit or -1, index of the conv weight in the parameter
+ * table, number of units}. */
+int vlsfr_mobilenet_unit_info(const vlsfr_mobilenet* n, int32_t k, int32_t* info /*[8]*/);
+int vlsfr_mobilenet_forward_units(const vlsfr_mobilenet* n, int32_t u0, int32_t u1, const void* x_in, const float* const* params,
+                                  float* const* running, const void* wcache, void* ctx, void* scratch, void* out, void* stream);
+int vlsfr_mobilenet_backward_units(const vlsfr_mobilenet* n, int32_t u0, int32_t u1, const void* dout, const float* const* params,
+                                   float* const* grads, const void* wcache, void* ctx, void* scratch, void* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 7c. torchvision-style ResNet executor (Bottleneck): same contract as section 7 for reference

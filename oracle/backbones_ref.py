@@ -216,6 +216,24 @@ def _bn_train(sd, name, x):
     return y
 
 
+def iresnet_block(sd, h, pre, first, E):
+    """IBasicBlock.forward (resnet_arcface.py:44-55): BN -> 3x3 -> BN -> PReLU -> 3x3(stride) -> BN, plus the identity or
+    (first block of a stage: stride 2) the 1x1-s2 + BN shortcut (:112-136)."""
+    conv = lambda t, name, stride, pad: E.R(F.conv2d(E.G(t), E.W(sd[name + ".weight"]), None, stride, pad))
+    stride = 2 if first else 1
+    o = E.R(_bn_train(sd, pre + ".bn1", h))
+    o = conv(o, pre + ".conv1", 1, 1)
+    o = E.R(F.prelu(_bn_train(sd, pre + ".bn2", o), sd[pre + ".prelu.weight"]))
+    o = conv(o, pre + ".conv2", stride, 1)
+    o = _bn_train(sd, pre + ".bn3", o)
+    if first:
+        idn = conv(h, pre + ".downsample.0", stride, 0)
+        idn = E.R(_bn_train(sd, pre + ".downsample.1", idn))
+    else:
+        idn = h
+    return E.R(o + idn)
+
+
 def iresnet_forward(sd, x, layers, emulate_bf16=False):
     E = Emu(emulate_bf16)
     conv = lambda h, name, stride, pad: E.R(F.conv2d(E.G(h), E.W(sd[name + ".weight"]), None, stride, pad))
@@ -223,19 +241,7 @@ def iresnet_forward(sd, x, layers, emulate_bf16=False):
     h = E.R(F.prelu(_bn_train(sd, "bn1", h), sd["prelu.weight"]))
     for li, nblk in enumerate(layers, start=1):
         for bi in range(nblk):
-            pre = "layer%d.%d" % (li, bi)
-            stride = 2 if bi == 0 else 1
-            o = E.R(_bn_train(sd, pre + ".bn1", h))
-            o = conv(o, pre + ".conv1", 1, 1)
-            o = E.R(F.prelu(_bn_train(sd, pre + ".bn2", o), sd[pre + ".prelu.weight"]))
-            o = conv(o, pre + ".conv2", stride, 1)
-            o = _bn_train(sd, pre + ".bn3", o)
-            if bi == 0:
-                idn = conv(h, pre + ".downsample.0", stride, 0)
-                idn = E.R(_bn_train(sd, pre + ".downsample.1", idn))
-            else:
-                idn = h
-            h = E.R(o + idn)
+            h = iresnet_block(sd, h, "layer%d.%d" % (li, bi), bi == 0, E)
     h = E.R(_bn_train(sd, "bn2", h))
     h = torch.flatten(h, 1)
     h = E.G(F.linear(h, E.W(sd["fc.weight"]), sd["fc.bias"]))
@@ -272,31 +278,38 @@ def resnet_std_forward(sd, x, layers, emulate_bf16=False):
     return F.normalize(h)
 
 
+def mobile_unit(sd, E, h, wname, bn, prelu, stride, pad, dw=False, res=None):
+    """conv -> BN (-> PReLU) (+ residual), one executor unit (ConvBlock, mobilefacenet_def.py:55-74): the convolution
+    output and the unit output are bf16 tensors on the device; depthwise filters are used as fp32 (csrc/dw.hip), MFMA
+    weights as bf16."""
+    w = sd[wname]
+    c = E.R(F.conv2d(E.G(h), w if dw else E.W(w), None, stride, pad, 1, w.shape[0] if dw else 1))
+    a = _bn_train(sd, bn, c)
+    if prelu is not None:
+        a = F.prelu(a, sd[prelu])
+    if res is not None:
+        a = a + res
+    return E.R(a)
+
+
+def mobile_bottleneck(sd, h, pre, stride, connect, E):
+    """BottleNeck.forward (mobilefacenet_def.py:27-52): 1x1 -> BN -> PReLU -> depthwise 3x3(stride) -> BN -> PReLU -> 1x1 -> BN,
+    `x + conv(x)` when stride 1 and equal widths."""
+    o = mobile_unit(sd, E, h, pre + ".0.weight", pre + ".1", pre + ".2.weight", 1, 0)
+    o = mobile_unit(sd, E, o, pre + ".3.weight", pre + ".4", pre + ".5.weight", stride, 1, dw=True)
+    return mobile_unit(sd, E, o, pre + ".6.weight", pre + ".7", None, 1, 0, res=h if connect else None)
+
+
 def mobilefacenet_forward(sd, x, emulate_bf16=False):
     E = Emu(emulate_bf16)
-
-    def unit(h, wname, bn, prelu, stride, pad, dw=False, res=None):
-        """conv -> BN (-> PReLU) (+ residual), one executor unit: the convolution output and the unit output are bf16
-        tensors on the device; depthwise filters are used as fp32 (csrc/dw.hip), MFMA weights as bf16."""
-        w = sd[wname]
-        c = E.R(F.conv2d(E.G(h), w if dw else E.W(w), None, stride, pad, 1, w.shape[0] if dw else 1))
-        a = _bn_train(sd, bn, c)
-        if prelu is not None:
-            a = F.prelu(a, sd[prelu])
-        if res is not None:
-            a = a + res
-        return E.R(a)
-
+    unit = lambda *a, **k: mobile_unit(sd, E, *a, **k)
     h = unit(E.X(x), "conv1.conv.weight", "conv1.bn", "conv1.prelu.weight", 2, 1)
     h = unit(h, "dw_conv1.conv.weight", "dw_conv1.bn", "dw_conv1.prelu.weight", 1, 1, dw=True)
     cur, bi = 64, 0
     for t, c, n, s in MOBILE_SETTING:
         for i in range(n):
-            pre = "blocks.%d.conv" % bi
             stride = s if i == 0 else 1
-            o = unit(h, pre + ".0.weight", pre + ".1", pre + ".2.weight", 1, 0)
-            o = unit(o, pre + ".3.weight", pre + ".4", pre + ".5.weight", stride, 1, dw=True)
-            h = unit(o, pre + ".6.weight", pre + ".7", None, 1, 0, res=h if (stride == 1 and cur == c) else None)
+            h = mobile_bottleneck(sd, h, "blocks.%d.conv" % bi, stride, stride == 1 and cur == c, E)
             cur = c
             bi += 1
     h = unit(h, "conv2.conv.weight", "conv2.bn", "conv2.prelu.weight", 1, 0)

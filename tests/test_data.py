@@ -76,3 +76,18 @@ def test_device_transform_matches_reference_arithmetic(tmp_path):
         assert inst_label.shape == (4,) and ids.shape == (2,) and len(set(ids.tolist())) == 2
         n += 1
     assert n == 3
+    # batches that MIX grey [H, W, 1] and colour [H, W, 3] records (store a: every 5th image is grey) — the reference
+    # converts sample by sample (util/lmdb_loader.py:111-127), so such batches are ordinary input
+    random.seed(9)
+    items = [multi[i] for i in (2, 3, 4, 5, 9)]                                  # records 4 and 9 are grey
+    assert sorted(set(int(it[0].shape[2]) for it in items)) == [1, 3]
+    images, labels, _ = device_collate("cuda")(items)
+    for k, it in enumerate(items):
+        assert np.array_equal(images[k].cpu().numpy(), loader_transform_ref(it[0].numpy(), it[1]))
+    random.seed(13)
+    b = DeviceBatcher(multi, pair, batch_size=8, device="cuda", n_batches=4, seed=1)
+    seen = 0
+    for inst, inst_label, i1, i2, ids in b:
+        assert inst.shape == (8, 3, 16, 16) and i1.shape == (4, 3, 16, 16) and bool(torch.isfinite(inst).all())
+        seen += 1
+    assert seen == 4

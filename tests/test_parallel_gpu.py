@@ -149,7 +149,7 @@ def test_two_rank_step_on_one_gpu():
         assert np.array_equal(res[1][mode]["pool"], res[0][mode]["pool"])
 
 
-def _train_worker(rank, port, out, tmp):
+def _train_worker(rank, port, out, tmp, pool="sharded"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK="0")
     import faulthandler
@@ -160,7 +160,7 @@ def _train_worker(rank, port, out, tmp):
     try:
         from vlsfr_amd.main import parse_args, train
         base = ["--net_type", "irtiny", "--feat_dim", "32", "--queue_size", "64", "--batch_size", "8", "--print_freq", "2",
-                "--iters_per_epoch", "4", "--num_class", "500", "--dist_backend", "gloo"]
+                "--iters_per_epoch", "4", "--num_class", "500", "--dist_backend", "gloo", "--pool", pool]
         res = {}
         for tag, extra in (("a", []), ("b", ["--resume", os.path.join(tmp, "a", "1.pt")])):
             net, loss = train(parse_args(base + ["--saved_dir", os.path.join(tmp, tag)] + extra), log=lambda *_: None)
@@ -177,34 +177,48 @@ def _train_worker(rank, port, out, tmp):
             dist.destroy_process_group()
 
 
-def test_two_rank_training_driver_checkpoints_shard_wise_and_resumes(tmp_path):
-    """main.train with WORLD_SIZE = 2 (gloo, one GPU): pool built shard-local, ZeRO-1 optimizer, shard-wise checkpoint
-    files (rank 0: model + allocator with fc = None; every rank: its pool slots), and `--resume` from them continues to
-    the state of the uninterrupted run."""
+@pytest.mark.parametrize("pool", ["sharded", "replicated"])
+def test_two_rank_training_driver_checkpoints_and_resumes(tmp_path, pool):
+    """main.train with WORLD_SIZE = 2 (gloo, one GPU), ZeRO-1 optimizer, checkpoint every 2 of 4 iterations, `--resume`
+    from the first one continues to the state of the uninterrupted run — including the optimizer's momenta, which live as
+    1 / world slices and must be gathered for the file on every rank, whichever pool form runs (the update made AFTER the
+    resume point is compared: a run that lost its momenta makes a ~45 % different one).
+    pool "sharded": pool built shard-local; files: rank 0 the model (fc / lru / qp = None), every rank its pool slots and the
+    replicated allocator state as arrays.  pool "replicated": one file in the reference's format (main.py:85)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_train_worker, args=(r, port, out, str(tmp_path))) for r in range(WORLD)]
+    procs = [ctx.Process(target=_train_worker, args=(r, port, out, str(tmp_path), pool)) for r in range(WORLD)]
     for p in procs:
         p.start()
     res = dict(out.get(timeout=300) for _ in range(WORLD))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res[0]["files"] == ["1.pool0.pt", "1.pool1.pt", "1.pt", "2.pool0.pt", "2.pool1.pt", "2.pt"]
     ck = torch.load(os.path.join(str(tmp_path), "a", "1.pt"), weights_only=True)
-    assert ck["fc"] is None and len(ck["qp"]) == 64
+    if pool == "sharded":
+        assert res[0]["files"] == ["1.pool0.pt", "1.pool1.pt", "1.pt", "2.pool0.pt", "2.pool1.pt", "2.pt"]
+        assert ck["fc"] is None and ck["lru"] is None and ck["qp"] is None
+        ps = torch.load(os.path.join(str(tmp_path), "a", "1.pool1.pt"), weights_only=True)
+        assert ps["fc_shard"].shape == (2, 32, 32) and ps["qp"].shape == (64,) and ps["lru_keys"].shape == ps["lru_slots"].shape
+    else:
+        assert res[0]["files"] == ["1.pt", "2.pt"]
+        assert ck["fc"].shape == (2, 64, 32) and len(ck["qp"]) == 64
+    mom = [v.get("momentum_buffer") for v in ck["resume"]["optimizer"]["state"].values()]
+    assert len(mom) > 10 and all(m is not None and float(m.abs().max()) > 0 for m in mom)     # the momenta are IN the file
+    w_ck = ck["state_dict"]["layer1.0.conv1.weight"].float().numpy()
     rel = lambda u, v: float(np.linalg.norm(u - v) / (np.linalg.norm(v) + 1e-30))
     for r in range(WORLD):
         a, b = res[r]["a"], res[r]["b"]
-        assert a["shard"].shape == (2, 32, 32)                               # each rank holds Q / 2 slots only
+        assert a["shard"].shape == ((2, 32, 32) if pool == "sharded" else (2, 64, 32))
         assert a["lru"] == b["lru"] and a["qp"] == b["qp"]
         assert abs(a["loss"] - b["loss"]) <= 2e-2 * abs(a["loss"])
         assert float(np.abs(a["shard"] - b["shard"]).max()) < 0.05
         assert rel(b["w"], a["w"]) < 2e-2
+        assert rel(b["w"] - w_ck, a["w"] - w_ck) < 0.2, rel(b["w"] - w_ck, a["w"] - w_ck)
     assert rel(res[1]["a"]["w"], res[0]["a"]["w"]) < 1e-6
 
 

@@ -244,11 +244,15 @@ def _emulated_oracle(net_type, D, Q, B, loss_type, margin, seed, layers, dtype):
     return o, sd, x, y, xl, yl
 
 
-def _emulated_pair(net_type, D, Q, B, loss_type, margin, seed, layers=None):
-    """The product FFC on the GPU and the float64 emulating oracle, same seeded weights, pool and batch."""
+def _emulated_pair(net_type, D, Q, B, loss_type, margin, seed, layers=None, head_dtype=None):
+    """The product FFC on the GPU and the float64 emulating oracle, same seeded weights, pool and batch.  head_dtype
+    None: the head in precise mode (split-bf16 products: fp32-class), so that the comparison isolates the backbone;
+    "bf16" / "fp8": the shadow sweeps the benchmarks run (csrc/head16.hip / head8.hip; D = 512)."""
     from vlsfr_amd.ffc import FFC
     o, sd, x, y, xl, yl = _emulated_oracle(net_type, D, Q, B, loss_type, margin, seed, layers, torch.float64)
-    m = FFC(net_type, D, Q, 32.0, loss_type, margin, 0.99, precise_head=True)
+    m = FFC(net_type, D, Q, 32.0, loss_type, margin, 0.99, precise_head=head_dtype is None)
+    if head_dtype is not None:
+        m.__dict__['head_dtype'] = head_dtype
     m.probe_net.load_state_dict(sd)
     m.gallery_net.load_state_dict(sd)
     m = m.cuda()
@@ -258,8 +262,14 @@ def _emulated_pair(net_type, D, Q, B, loss_type, margin, seed, layers=None):
 
 # (net, feat_dim, pool slots, batch_size): the two backbones the bench runs (ir50 = BASELINE configs[1], ir100 = the
 # metric) at the batch the float64 oracle finishes in seconds, the 4-block iResNet and MobileFaceNet at batch 32.
-EMU_CASES = [("irtiny", 64, 512, 32, (1, 1, 1, 1)), ("mobile", 128, 1000, 32, None), ("ir50", 512, 2048, 8, None),
-             ("ir100", 512, 2048, 8, None), ("rtiny", 64, 512, 16, None)]
+# "mobile512-fp8" is BASELINE configs[4] (C5) in one piece: MobileFaceNet, D = 512, the e4m3 class matmul.
+EMU_CASES = [("irtiny", 64, 512, 32, (1, 1, 1, 1), None), ("mobile", 128, 1000, 32, None, None), ("ir50", 512, 2048, 8, None, None),
+             ("ir100", 512, 2048, 8, None, None), ("rtiny", 64, 512, 16, None, None),
+             ("mobile", 512, 4096, 32, None, "fp8"), ("mobile", 512, 4096, 32, None, "bf16")]
+EMU_IDS = [c[0] + ("%d-%s" % (c[1], c[5]) if c[5] else "") for c in EMU_CASES]
+# What the reduced-precision class matmul may add to the backbone's band (bf16 loss 2e-2, fp8 loss 5e-2 and
+# cosine >= 0.99; tests/test_head_gpu.py measures the heads alone: loss 3e-3 / 5e-3, dL/dp rel-L2 <= 8 % for fp8).
+HEAD_EXTRA = {None: dict(loss=0.0, g=0.0), "bf16": dict(loss=3e-3, g=2e-2), "fp8": dict(loss=5e-3, g=8e-2)}
 # Absolute caps on top of the self-calibrated band below: loss, embedding cosine (>= 0.999 for bf16), relative
 # L2 of the whole gradient.  (The per-tensor bound is purely band-relative: a tensor's own band can be large where its
 # exact gradient is tiny.)
@@ -278,8 +288,8 @@ def _grad_errors(got, ref):
     return float(np.sqrt(num / den)), each
 
 
-@pytest.mark.parametrize("net_type,D,Q,B,layers", EMU_CASES, ids=[c[0] for c in EMU_CASES])
-def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
+@pytest.mark.parametrize("net_type,D,Q,B,layers,head_dtype", EMU_CASES, ids=EMU_IDS)
+def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers, head_dtype):
     """One whole training step (probe / gallery backbones, both DCP passes, backward, SGD-nesterov, EMA) of the
     benchmarked networks against the float64 oracle that rounds to bf16 exactly where the device stores bf16: loss,
     embeddings, EVERY gradient tensor, post-step parameters, gallery EMA, LRU / queue_position state.
@@ -295,8 +305,8 @@ def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
     from vlsfr_amd.optim.fused import FusedSGD
     from oracle import ffc_ref
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
-    m, o, x, y, xl, yl = _emulated_pair(net_type, D, Q, B, "Arc", 0.5, 31, layers)
-    cap = EMU_CAP[net_type]
+    m, o, x, y, xl, yl = _emulated_pair(net_type, D, Q, B, "Arc", 0.5, 31, layers, head_dtype)
+    cap, extra = EMU_CAP[net_type], HEAD_EXTRA[head_dtype]
     embs = []
     hook = m.probe_net.register_forward_hook(lambda mod, i, out: embs.append(out.detach().cpu()))
     opt = FusedSGD([p for p in m.parameters() if p.requires_grad], 0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
@@ -323,13 +333,15 @@ def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
           "%s gpu %.2e band %.2e" % (net_type, float(loss.detach()), float(want.detach()), float(w32.detach()), g_all,
                                      noise_all, worst, g_each[worst], noise_each[worst]))
     np.testing.assert_allclose(float(loss.detach()), float(want.detach()),
-                               rtol=max(cap["loss"], 3 * abs(float(w32.detach()) - float(want.detach())) / float(want.detach())))
+                               rtol=extra["loss"] + max(cap["loss"], 3 * abs(float(w32.detach()) - float(want.detach())) / float(want.detach())))
     assert min_cos(embs[0], emb_x) >= cap["cos"]
     assert m.lru.state_dict() == o.lru.state_dict()
     assert m.queue_position_dict.values() == o.qp
-    assert g_all <= min(cap["g_all"], max(1.5 * noise_all, 5e-3)), (g_all, noise_all)
+    if head_dtype is not None:
+        assert m._ensure_head().shadow.t.get(head_dtype) is not None            # the shadow sweep is what ran
+    assert g_all <= extra["g"] + min(cap["g_all"], max(1.5 * noise_all, 5e-3)), (g_all, noise_all)
     for k, e in g_each.items():
-        assert e <= 2.0 * max(noise_each[k], noise_all, 2e-3), (k, e, noise_each[k], noise_all)
+        assert e <= extra["g"] + 2.0 * max(noise_each[k], noise_all, 2e-3), (k, e, noise_each[k], noise_all)
     # SGD-nesterov step + what the EMA made of the gallery net (the EMA ran inside forward, before the step)
     ps = o.parameters()
     before = {k: v.detach().clone() for k, v in o.probe.items() if bb.trainable(k, net_type)}
@@ -342,7 +354,7 @@ def test_step_vs_bf16_emulating_oracle(net_type, D, Q, B, layers):
             gk = pn[k].detach().double().cpu().numpy()
             num += float(((gk - v.detach().numpy()) ** 2).sum())
             den += float(((v.detach() - before[k]).numpy() ** 2).sum())
-    assert np.sqrt(num / den) <= min(cap["g_all"], max(1.5 * noise_all, 5e-3))     # error relative to the size of the update
+    assert np.sqrt(num / den) <= extra["g"] + min(cap["g_all"], max(1.5 * noise_all, 5e-3))     # error relative to the size of the update
     gp = dict(m.gallery_net.named_parameters())
     for k, v in o.gallery.items():
         if not bb.is_buffer(k):
@@ -505,3 +517,81 @@ def test_weight_gradients_on_a_side_stream_do_not_change_the_step():
     assert d <= max(4 * noise, 5e-2)
     assert abs(l0 - l1) <= max(4 * abs(l0 - l0b), 2e-3 * abs(l0))
     assert s0 == s1 and (qp0 == qp1).all()
+
+
+# (net_type, feat_dim, batch): the full-depth members of the three families that no other test builds — the reference's
+# default `--net_type r50` ([3, 4, 6, 3] Bottlenecks at 224 x 224, model/resnet_std.py:242-251) and iresnet34 / iresnet200
+# (model/resnet_arcface.py:167-184)
+FULL_DEPTH = [("r50", 512, 4), ("ir34", 512, 8), ("ir200", 512, 4)]
+
+
+@pytest.mark.parametrize("net_type,D,B", FULL_DEPTH, ids=[c[0] for c in FULL_DEPTH])
+def test_full_depth_backbone_step(net_type, D, B):
+    """One whole FFC step through the full-depth net: the probe embeddings of the first pass against the float64 oracle with
+    bf16 storage emulation (forward only — cosine >= 0.999), the loss against the oracle's (rtol 2e-2, SURVEY
+    8d), the state-dict layout against the oracle's restatement of the reference constructors, finite gradients on every
+    trainable parameter, a finite SGD step, LRU / queue_position state.  (Gradient parity of these kernels and of the
+    executors' wiring: tests/test_blocks_gpu.py and the emulating-oracle steps above.)"""
+    from vlsfr_amd.ffc import FFC
+    from vlsfr_amd.optim.fused import FusedSGD
+    from oracle import ffc_ref
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    Q = 256
+    o, sd, x, y, xl, yl = _emulated_oracle(net_type, D, Q, B, "Arc", 0.5, 41, None, torch.float64)
+    hw = 224 if net_type == "r50" else 112
+    rng = np.random.default_rng(41)
+    x = common.images_from_u8(common.synth_images_u8(rng, B, hw=hw))
+    y = common.images_from_u8(common.synth_images_u8(rng, B, hw=hw))
+    if net_type == "r50":
+        # 16 Bottlenecks whose last BatchNorm has gamma ~ 1 put a randomly initialised ReLU net at a point where bf16 storage
+        # alone moves the embedding by cos 0.66 and fp32-vs-fp64 summation by cos 0.91 (scripts/diag_rstd_depth.py; the
+        # executor sits ON that band, as it does at gamma x 0.1: 0.99968 vs 0.99967) — nothing can be pinned there.  Small
+        # residual-branch gammas (what resnet_std.py:156-161's zero_init_residual aims at, and what trained nets have)
+        # give a well-conditioned point.
+        for k in sd:
+            if k.endswith("bn3.weight"):
+                sd[k] = sd[k] * 0.1
+        o.probe = {k: (v.double().requires_grad_(bb.trainable(k, net_type)) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        o.gallery = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    m = FFC(net_type, D, Q, 32.0, "Arc", 0.5, 0.99, precise_head=True)
+    assert set(m.probe_net.state_dict().keys()) == set(sd.keys())
+    assert all(tuple(m.probe_net.state_dict()[k].shape) == tuple(v.shape) for k, v in sd.items())
+    m.probe_net.load_state_dict(sd)
+    m.gallery_net.load_state_dict(sd)
+    m = m.cuda()
+    m.queue.copy_(o.queue.float())
+    embs = []
+    hook = m.probe_net.register_forward_hook(lambda mod, i, out: embs.append(out.detach().cpu()))
+    opt = FusedSGD([p for p in m.parameters() if p.requires_grad], 0.1, momentum=0.9, weight_decay=1e-4, nesterov=True)
+    opt.zero_grad()
+    loss = m(x.cuda(), y.cuda(), xl, yl)
+    loss.backward()
+    hook.remove()
+    torch.cuda.synchronize()
+    assert embs[0].shape == (B, D) and embs[1].shape == (B, D)
+    with torch.no_grad():
+        emb_x = o.fwd({k: v.detach().clone() for k, v in o.probe.items()}, x.double())
+        emb_32 = o.fwd({k: (v.detach().float() if v.is_floating_point() else v.clone()) for k, v in o.probe.items()}, x.float())
+    c, band = min_cos(embs[0], emb_x), min_cos(emb_32, emb_x)
+    print("%s full depth: embedding cosine vs the emulating float64 oracle %.6f (the oracle in fp32 vs fp64: %.6f), loss %.5f" %
+          (net_type, c, band, float(loss.detach())))
+    # SURVEY 8d: cosine >= 0.999 — or, where 200 layers at batch 4 amplify summation-order noise beyond that, within twice
+    # what an fp32 evaluation of the same rounding-point model deviates from its fp64 self
+    assert 1.0 - c <= max(1e-3, 2.0 * (1.0 - band)), (c, band)
+    np.testing.assert_allclose(embs[0].norm(dim=1).numpy(), 1.0, rtol=1e-5)
+    assert np.isfinite(float(loss.detach()))
+    n_grad = 0
+    for k, p in m.probe_net.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+            n_grad += int(float(p.grad.abs().max()) > 0)
+    assert n_grad >= 0.9 * sum(1 for p in m.probe_net.parameters() if p.requires_grad)
+    opt.step()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(p).all()) for p in m.probe_net.parameters())
+    # bookkeeping is label-driven: identical to the oracle's, which runs both passes on the host in float64 (forward only)
+    with torch.no_grad():
+        want = o.forward(x.double(), y.double(), xl, yl)
+    np.testing.assert_allclose(float(loss.detach()), float(want), rtol=2e-2)
+    assert m.lru.state_dict() == o.lru.state_dict()
+    assert m.queue_position_dict.values() == o.qp

@@ -296,6 +296,60 @@ int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M,
                                  next ? (float*)(ctx + next->off_red) : nullptr, st);
 }
 
+// IBasicBlock.forward (resnet_arcface.py:44-55) of block k on the activation `cur` (bf16 NHWC; its statistics are already in
+// bn1's sums: every BatchNorm's batch statistics are accumulated by the kernel that PRODUCES its input)
+int forward_block(const vlsfr_iresnet* n, int k, const char* cur, const float* const* params, float* const* running, char* ctx,
+                  const char* wc, const Scratch& sc, void* st) {
+  const int B = n->B;
+  auto sums_of = [&](const Bn& b) { return (float*)(ctx + b.off_sums); };
+  const Block& b = n->blocks[k];
+  const Bn& next_bn = (size_t)k + 1 < n->blocks.size() ? n->blocks[k + 1].bn1 : n->bn_last;
+  const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
+  RUN(bn_forward(b.bn1, cur, ctx + b.a1, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
+  RUN(vlsfr_conv2d_fwd(&b.conv1.d, ctx + b.a1, wc + b.conv1.off_wb, ctx + b.c1, 1, 0, sums_of(b.bn2), st));
+  RUN(bn_forward(b.bn2, ctx + b.c1, ctx + b.a2, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
+  RUN(vlsfr_conv2d_fwd(&b.conv2.d, ctx + b.a2, wc + b.conv2.off_wb, ctx + b.c2, 1, 0, sums_of(b.bn3), st));
+  const void* idn = cur;
+  if (b.has_ds) {
+    RUN(vlsfr_conv2d_fwd(&b.convd.d, cur, wc + b.convd.off_wb, ctx + b.cs, 1, 0, sums_of(b.bnd), st));
+    RUN(bn_forward(b.bnd, ctx + b.cs, sc.idn, Mout, b.Ho * b.Wo, nullptr, nullptr, 0, params, running, ctx, st));
+    idn = sc.idn;
+  }
+  return bn_forward(b.bn3, ctx + b.c2, ctx + b.out, Mout, b.Ho * b.Wo, idn, sums_of(next_bn), 0, params, running, ctx, st);
+}
+
+// Backward of block k: dout = gradient of the block output (in sc.g[cur_i]); leaves the gradient of the block input in
+// sc.g[(cur_i + 1) % 3].  `chained`: bn3's reduction came with the kernel that wrote dout; chain_prev: accumulate the
+// reduction of block k - 1's bn3 while writing this block's input gradient (vlsfr_bn_backward_chain).
+int backward_block(const vlsfr_iresnet* n, int k, int cur_i, bool chained, bool chain_prev, const float* const* params,
+                   float* const* grads, char* ctx, const char* wc, const Scratch& sc, void* st) {
+  const int B = n->B;
+  const Block& b = n->blocks[k];
+  const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
+  const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
+  char* t1 = sc.g[(cur_i + 1) % 3];
+  char* t2 = sc.g[(cur_i + 2) % 3];
+  const char* dout = sc.g[cur_i];
+  // main branch
+  RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st, chained ? 1 : 0));
+  RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
+  RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
+  RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st));   // d c1
+  RUN(vlsfr_conv2d_wgrad_ws(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
+  RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, st));                 // d a1 (in t2)
+  const char* add = dout;
+  if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
+    RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
+    RUN(vlsfr_conv2d_wgrad_ws(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
+    RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
+    add = sc.idn;
+  }
+  // d x_in = bn1 backward of d a1, plus the shortcut gradient; x_in is the output of block k - 1, so this IS the dY of
+  // that block's bn3: its reduction is accumulated here (one read of c2 instead of a kernel reading dout and c2)
+  return bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st, 0,
+                     chain_prev ? &n->blocks[k - 1].bn3 : nullptr, chain_prev ? ctx + n->blocks[k - 1].c2 : nullptr);
+}
+
 }  // namespace
 
 extern "C" {
@@ -364,23 +418,9 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
   RUN(bn_forward(n->stem_bn, ctx + n->off_c0, ctx + n->off_a0, (int64_t)B * S * S, S * S, nullptr,
                  sums_of(n->blocks[0].bn1), 0, params, running, ctx, st));
   const char* cur = ctx + n->off_a0;
-  for (size_t k = 0; k < n->blocks.size(); ++k) {   // IBasicBlock.forward, resnet_arcface.py:44-55
-    const Block& b = n->blocks[k];
-    const Bn& next_bn = k + 1 < n->blocks.size() ? n->blocks[k + 1].bn1 : n->bn_last;
-    const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
-    RUN(bn_forward(b.bn1, cur, ctx + b.a1, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
-    RUN(vlsfr_conv2d_fwd(&b.conv1.d, ctx + b.a1, wc + b.conv1.off_wb, ctx + b.c1, 1, 0, sums_of(b.bn2), st));
-    RUN(bn_forward(b.bn2, ctx + b.c1, ctx + b.a2, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
-    RUN(vlsfr_conv2d_fwd(&b.conv2.d, ctx + b.a2, wc + b.conv2.off_wb, ctx + b.c2, 1, 0, sums_of(b.bn3), st));
-    const void* idn = cur;
-    if (b.has_ds) {
-      RUN(vlsfr_conv2d_fwd(&b.convd.d, cur, wc + b.convd.off_wb, ctx + b.cs, 1, 0, sums_of(b.bnd), st));
-      RUN(bn_forward(b.bnd, ctx + b.cs, sc.idn, Mout, b.Ho * b.Wo, nullptr, nullptr, 0, params, running, ctx, st));
-      idn = sc.idn;
-    }
-    RUN(bn_forward(b.bn3, ctx + b.c2, ctx + b.out, Mout, b.Ho * b.Wo, idn, sums_of(next_bn), 0, params, running, ctx,
-                   st));
-    cur = ctx + b.out;
+  for (size_t k = 0; k < n->blocks.size(); ++k) {
+    RUN(forward_block(n, (int)k, cur, params, running, ctx, wc, sc, st));
+    cur = ctx + n->blocks[k].out;
   }
   // bn2 -> flatten -> fc -> features -> normalise (resnet_arcface.py:147-151)
   const Block& last = n->blocks.back();
@@ -444,31 +484,9 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   int stage = 4, left = n->layers[3];   // blocks of the current stage still to go
   bool chained = false;                 // bn3 of the current block already has its reduction
   for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
-    const Block& b = n->blocks[k];
-    const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
-    const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
-    char* t1 = sc.g[(cur_i + 1) % 3];
-    char* t2 = sc.g[(cur_i + 2) % 3];
-    const char* dout = sc.g[cur_i];
-    // main branch (the reduction of bn3 came with the kernel that wrote dout: bn1 of block k + 1, below)
-    RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st, chained ? 1 : 0));
-    RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-    RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
-    RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st));   // d c1
-    RUN(vlsfr_conv2d_wgrad_ws(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-    RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, st));                 // d a1 (in t2)
-    const char* add = dout;
-    if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
-      RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
-      RUN(vlsfr_conv2d_wgrad_ws(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-      RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
-      add = sc.idn;
-    }
-    // d x_in = bn1 backward of d a1, plus the shortcut gradient; x_in is the output of block k - 1, so this IS the dY of
-    // that block's bn3: its reduction is accumulated here (one read of c2 instead of a kernel reading dout and c2)
-    chained = g_bn_chain && k > 0;
-    RUN(bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st, 0, chained ? &n->blocks[k - 1].bn3 : nullptr,
-                    chained ? ctx + n->blocks[k - 1].c2 : nullptr));
+    const bool chain_prev = g_bn_chain && k > 0;
+    RUN(backward_block(n, k, cur_i, chained, chain_prev, params, grads, ctx, wc, sc, st));
+    chained = chain_prev;
     cur_i = (cur_i + 1) % 3;   // t1 is the new dcur
     if (--left == 0 && stage > 1) {   // stage 4, 3, 2 complete -> buckets 1, 2, 3 (stage 1 goes with the stem)
       RUN(signal(5 - stage));
@@ -485,6 +503,72 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   RUN(vlsfr_conv2d_wgrad_ws(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
   RUN(vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, st));
   return signal(4);
+}
+
+// ---- teacher-forced execution of a range of blocks (parity tests of the executor wiring) --------------------------------
+// vlsfr_iresnet_forward_blocks runs IBasicBlock k0 .. k1 - 1 exactly as vlsfr_iresnet_forward does (same kernels, same
+// context slots), but from an activation handed in by the caller instead of the output of the layers in front; the
+// backward twin starts from a caller-supplied output gradient.  One block does not amplify rounding noise the way 49
+// stacked train-mode BatchNorm blocks do, so residual / downsample / PReLU / BatchNorm gradient routing can be held to
+// a per-tensor tolerance instead of the whole-network band.
+int vlsfr_iresnet_block_info(const vlsfr_iresnet* n, int32_t k, int32_t* info /*[8]*/) {
+  if (!n || !info || k < 0 || k >= (int)n->blocks.size()) return fail(VLSFR_EINVAL, "vlsfr_iresnet_block_info: bad argument");
+  const Block& b = n->blocks[k];
+  const int32_t v[8] = {b.cin, b.planes, b.H, b.Ho, b.stride, b.has_ds ? 1 : 0, b.bn1.p_w, (int32_t)n->blocks.size()};
+  std::memcpy(info, v, sizeof(v));
+  return VLSFR_OK;
+}
+
+int vlsfr_iresnet_forward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1, const void* x_in, const float* const* params,
+                                 float* const* running, const void* wcache, void* ctx_v, void* scratch, void* out, void* st) {
+  if (!n || !x_in || !params || !wcache || !ctx_v || !scratch || !out || k0 < 0 || k1 <= k0 || k1 > (int)n->blocks.size())
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_forward_blocks: bad argument");
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  Scratch sc = carve(n, scratch);
+  hipStream_t s = (hipStream_t)st;
+  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, s);
+  const Block& first = n->blocks[k0];
+  char* cur = k0 > 0 ? ctx + n->blocks[k0 - 1].out : ctx + n->off_a0;
+  const int64_t Min = (int64_t)n->B * first.H * first.W;
+  if (e == hipSuccess) e = hipMemcpyAsync(cur, x_in, (size_t)Min * first.cin * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward_blocks: %s", hipGetErrorString(e));
+  RUN(vlsfr_bn_stats(cur, Min, first.cin, (float*)(ctx + first.bn1.off_sums), st));
+  for (int k = k0; k < k1; ++k) {
+    RUN(forward_block(n, k, cur, params, running, ctx, wc, sc, st));
+    cur = ctx + n->blocks[k].out;
+  }
+  const Block& lastb = n->blocks[k1 - 1];
+  e = hipMemcpyAsync(out, cur, (size_t)n->B * lastb.Ho * lastb.Wo * lastb.planes * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward_blocks: copy: %s", hipGetErrorString(e));
+  return VLSFR_OK;
+}
+
+int vlsfr_iresnet_backward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1, const void* dout, const float* const* params,
+                                  float* const* grads, const void* wcache, void* ctx_v, void* scratch, void* dx, void* st) {
+  if (!n || !dout || !params || !grads || !wcache || !ctx_v || !scratch || !dx || k0 < 0 || k1 <= k0 || k1 > (int)n->blocks.size())
+    return fail(VLSFR_EINVAL, "vlsfr_iresnet_backward_blocks: bad argument");
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  Scratch sc = carve(n, scratch);
+  hipStream_t s = (hipStream_t)st;
+  hipError_t e = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, s);
+  const Block& lastb = n->blocks[k1 - 1];
+  int cur_i = 0;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(sc.g[cur_i], dout, (size_t)n->B * lastb.Ho * lastb.Wo * lastb.planes * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_blocks: %s", hipGetErrorString(e));
+  bool chained = false;
+  for (int k = k1 - 1; k >= k0; --k) {
+    const bool chain_prev = g_bn_chain && k > k0;     // inside the range only: block k0 - 1 did not run
+    RUN(backward_block(n, k, cur_i, chained, chain_prev, params, grads, ctx, wc, sc, st));
+    chained = chain_prev;
+    cur_i = (cur_i + 1) % 3;
+  }
+  const Block& first = n->blocks[k0];
+  e = hipMemcpyAsync(dx, sc.g[cur_i], (size_t)n->B * first.H * first.W * first.cin * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_blocks: copy: %s", hipGetErrorString(e));
+  return VLSFR_OK;
 }
 
 // ---- backward pass with the weight gradients on a second stream -------------------------------------------------

@@ -194,6 +194,88 @@ Scratch carve(const vlsfr_mobilenet* n, void* scratch) {
   return s;
 }
 
+// conv -> BN -> (PReLU) (+ residual) of unit k (ConvBlock / the three stages of a BottleNeck, mobilefacenet_def.py:27-74)
+int forward_unit(const vlsfr_mobilenet* n, int k, const float* x_nchw, const float* const* params, float* const* running,
+                 char* ctx, const char* wc, void* st) {
+  const Unit& u = n->units[k];
+  float* sums = (float*)(ctx + u.off_sums);
+  const char* in = u.in_unit >= 0 ? ctx + n->units[u.in_unit].a : nullptr;
+  if (u.kind == STEM) {
+    RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, n->B, n->S, n->S, 2, st));
+    RUN(vlsfr_conv2d_fwd(&u.d, ctx + n->off_cols, wc + u.off_wb, ctx + u.c, 1, 0, sums, st));
+  } else if (u.kind == PW) {
+    RUN(vlsfr_conv2d_fwd(&u.d, in, wc + u.off_wb, ctx + u.c, 1, 0, sums, st));
+  } else {
+    RUN(vlsfr_dwconv_fwd(&u.d, in, params[u.p_w], ctx + u.c, sums, st));
+  }
+  const int64_t M = (int64_t)n->B * u.Ho * u.Wo;
+  const void* res = u.res_unit >= 0 ? ctx + n->units[u.res_unit].a : nullptr;
+  return vlsfr_bn_apply(ctx + u.c, ctx + u.a, M, u.d.Cout, u.Ho * u.Wo, sums, params[u.p_g], params[u.p_b],
+                        u.p_slope >= 0 ? params[u.p_slope] : nullptr, res, (float*)(ctx + u.off_mean),
+                        (float*)(ctx + u.off_invstd), running ? running[2 * u.run] : nullptr,
+                        running ? running[2 * u.run + 1] : nullptr, BN_EPS, BN_MOM, nullptr, 0, st);
+}
+
+// Backward walk over units k_hi .. k_lo (descending).  In: sc.g[*cur] = d(output of unit k_hi).  Out: sc.g[*cur] =
+// d(input of unit k_lo) unless k_lo is the stem; a residual source in front of the range (unit k_lo - 1 feeding a later
+// residual add) leaves its extra gradient in sc.g[*pend_buf] with *pend_unit = k_lo - 1.
+int backward_units(const vlsfr_mobilenet* n, int k_hi, int k_lo, int* cur_io, int* pend_unit_io, int* pend_buf_io,
+                   const float* const* params, float* const* grads, char* ctx, const char* wc, const Scratch& sc, void* st) {
+  int cur = *cur_io, pend_unit = *pend_unit_io, pend_buf = *pend_buf_io;
+  for (int k = k_hi; k >= k_lo; --k) {
+    const Unit& u = n->units[k];
+    const int64_t M = (int64_t)n->B * u.Ho * u.Wo;
+    // free buffers: any of the 4 that is neither `cur` nor `pend_buf`
+    int t1 = -1, t2 = -1;
+    for (int i = 0; i < 4; ++i)
+      if (i != cur && i != pend_buf) {
+        if (t1 < 0) t1 = i;
+        else if (t2 < 0) t2 = i;
+      }
+    if (pend_unit == k) {   // this unit's output also fed a later residual add: sum both gradients
+      RUN(vlsfr_add_bf16(sc.g[cur], sc.g[pend_buf], sc.g[cur], M * u.d.Cout, st));
+      pend_unit = -1;
+      pend_buf = -1;
+      t1 = t2 = -1;
+      for (int i = 0; i < 4; ++i)
+        if (i != cur) {
+          if (t1 < 0) t1 = i;
+          else if (t2 < 0) t2 = i;
+        }
+    }
+    if (u.res_unit >= 0) {   // out = bn(c) + a[res]: the residual source receives d(out) as is
+      pend_unit = u.res_unit;
+      pend_buf = cur;        // keep d(out) alive; the BN backward below writes elsewhere
+    }
+    char* dc = sc.g[t1];
+    RUN(vlsfr_bn_backward(sc.g[cur], ctx + u.c, dc, M, u.d.Cout, u.Ho * u.Wo, (const float*)(ctx + u.off_mean),
+                          (const float*)(ctx + u.off_invstd), params[u.p_g], params[u.p_b],
+                          u.p_slope >= 0 ? params[u.p_slope] : nullptr, (float*)(ctx + u.off_red), nullptr,
+                          grads[u.p_g], grads[u.p_b], u.p_slope >= 0 ? grads[u.p_slope] : nullptr, 0, st));
+    const char* in = u.in_unit >= 0 ? ctx + n->units[u.in_unit].a : nullptr;
+    if (u.kind == STEM) {
+      hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
+      if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward: memset: %s", hipGetErrorString(e));
+      RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
+      RUN(vlsfr_unpad_add(sc.stem_dw, grads[u.p_w], 64, 32, 27, st));
+      break;
+    }
+    char* din = sc.g[t2];
+    if (u.kind == PW) {
+      RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, in, grads[u.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
+      RUN(vlsfr_conv2d_dgrad(&u.d, dc, wc + u.off_wT, din, st));
+    } else {
+      RUN(vlsfr_dwconv_wgrad_ws(&u.d, dc, in, grads[u.p_w], sc.wgrad_ws, n->wgrad_ws, st));
+      RUN(vlsfr_dwconv_dgrad(&u.d, dc, params[u.p_w], din, st));
+    }
+    cur = t2;
+  }
+  *cur_io = cur;
+  *pend_unit_io = pend_unit;
+  *pend_buf_io = pend_buf;
+  return VLSFR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -243,25 +325,7 @@ int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const
   const char* wc = (const char*)wcache;
   hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_forward: memset: %s", hipGetErrorString(e));
-  for (size_t k = 0; k < n->units.size(); ++k) {
-    const Unit& u = n->units[k];
-    float* sums = (float*)(ctx + u.off_sums);
-    const char* in = u.in_unit >= 0 ? ctx + n->units[u.in_unit].a : nullptr;
-    if (u.kind == STEM) {
-      RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, n->B, n->S, n->S, 2, st));
-      RUN(vlsfr_conv2d_fwd(&u.d, ctx + n->off_cols, wc + u.off_wb, ctx + u.c, 1, 0, sums, st));
-    } else if (u.kind == PW) {
-      RUN(vlsfr_conv2d_fwd(&u.d, in, wc + u.off_wb, ctx + u.c, 1, 0, sums, st));
-    } else {
-      RUN(vlsfr_dwconv_fwd(&u.d, in, params[u.p_w], ctx + u.c, sums, st));
-    }
-    const int64_t M = (int64_t)n->B * u.Ho * u.Wo;
-    const void* res = u.res_unit >= 0 ? ctx + n->units[u.res_unit].a : nullptr;
-    RUN(vlsfr_bn_apply(ctx + u.c, ctx + u.a, M, u.d.Cout, u.Ho * u.Wo, sums, params[u.p_g], params[u.p_b],
-                       u.p_slope >= 0 ? params[u.p_slope] : nullptr, res, (float*)(ctx + u.off_mean),
-                       (float*)(ctx + u.off_invstd), running ? running[2 * u.run] : nullptr,
-                       running ? running[2 * u.run + 1] : nullptr, BN_EPS, BN_MOM, nullptr, 0, st));
-  }
+  for (size_t k = 0; k < n->units.size(); ++k) RUN(forward_unit(n, (int)k, x_nchw, params, running, ctx, wc, st));
   // linear1 (1x1 on the 1x1 map) -> BN over the batch -> flatten -> normalise (mobilefacenet_def.py:112-114)
   const Unit& l7 = n->units.back();
   RUN(vlsfr_conv2d_fwd(&n->l1d, ctx + l7.a, wc + n->l1_wb, ctx + n->off_fc, 1, 1, nullptr, st));
@@ -295,54 +359,64 @@ int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const 
   RUN(vlsfr_conv2d_dgrad(&n->l1d, sc.dfc, wc + n->l1_wT, sc.g[cur], st));
   int pend_unit = -1;
   int pend_buf = -1;
-  for (int k = (int)n->units.size() - 1; k >= 0; --k) {
-    const Unit& u = n->units[k];
-    const int64_t M = (int64_t)n->B * u.Ho * u.Wo;
-    // free buffers: any of the 4 that is neither `cur` nor `pend_buf`
-    int t1 = -1, t2 = -1;
-    for (int i = 0; i < 4; ++i)
-      if (i != cur && i != pend_buf) {
-        if (t1 < 0) t1 = i;
-        else if (t2 < 0) t2 = i;
-      }
-    if (pend_unit == k) {   // this unit's output also fed a later residual add: sum both gradients
-      RUN(vlsfr_add_bf16(sc.g[cur], sc.g[pend_buf], sc.g[cur], M * u.d.Cout, st));
-      pend_unit = -1;
-      pend_buf = -1;
-      t1 = t2 = -1;
-      for (int i = 0; i < 4; ++i)
-        if (i != cur) {
-          if (t1 < 0) t1 = i;
-          else if (t2 < 0) t2 = i;
-        }
-    }
-    if (u.res_unit >= 0) {   // out = bn(c) + a[res]: the residual source receives d(out) as is
-      pend_unit = u.res_unit;
-      pend_buf = cur;        // keep d(out) alive; the BN backward below writes elsewhere
-    }
-    char* dc = sc.g[t1];
-    RUN(vlsfr_bn_backward(sc.g[cur], ctx + u.c, dc, M, u.d.Cout, u.Ho * u.Wo, (const float*)(ctx + u.off_mean),
-                          (const float*)(ctx + u.off_invstd), params[u.p_g], params[u.p_b],
-                          u.p_slope >= 0 ? params[u.p_slope] : nullptr, (float*)(ctx + u.off_red), nullptr,
-                          grads[u.p_g], grads[u.p_b], u.p_slope >= 0 ? grads[u.p_slope] : nullptr, 0, st));
-    const char* in = u.in_unit >= 0 ? ctx + n->units[u.in_unit].a : nullptr;
-    if (u.kind == STEM) {
-      e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
-      if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward: memset: %s", hipGetErrorString(e));
-      RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
-      RUN(vlsfr_unpad_add(sc.stem_dw, grads[u.p_w], 64, 32, 27, st));
-      break;
-    }
-    char* din = sc.g[t2];
-    if (u.kind == PW) {
-      RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, in, grads[u.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-      RUN(vlsfr_conv2d_dgrad(&u.d, dc, wc + u.off_wT, din, st));
-    } else {
-      RUN(vlsfr_dwconv_wgrad_ws(&u.d, dc, in, grads[u.p_w], sc.wgrad_ws, n->wgrad_ws, st));
-      RUN(vlsfr_dwconv_dgrad(&u.d, dc, params[u.p_w], din, st));
-    }
-    cur = t2;
+  RUN(backward_units(n, (int)n->units.size() - 1, 0, &cur, &pend_unit, &pend_buf, params, grads, ctx, wc, sc, st));
+  return VLSFR_OK;
+}
+
+// ---- teacher-forced execution of units u0 .. u1 - 1 (parity tests of the executor wiring; see vlsfr_iresnet_forward_blocks).
+// A BottleNeck (mobilefacenet_def.py:27-52) is three consecutive units (1x1, depthwise 3x3, 1x1 linear [+ residual]);
+// x_in is the output of unit u0 - 1 (u0 >= 1), bf16 NHWC.
+int vlsfr_mobilenet_unit_info(const vlsfr_mobilenet* n, int32_t k, int32_t* info /*[8]*/) {
+  if (!n || !info || k < 0 || k >= (int)n->units.size()) return fail(VLSFR_EINVAL, "vlsfr_mobilenet_unit_info: bad argument");
+  const Unit& u = n->units[k];
+  const int32_t v[8] = {(int32_t)u.kind, u.d.Cin, u.d.Cout, u.d.H, u.Ho, u.res_unit, u.p_w, (int32_t)n->units.size()};
+  std::memcpy(info, v, sizeof(v));
+  return VLSFR_OK;
+}
+
+int vlsfr_mobilenet_forward_units(const vlsfr_mobilenet* n, int32_t u0, int32_t u1, const void* x_in, const float* const* params,
+                                  float* const* running, const void* wcache, void* ctx_v, void* scratch, void* out, void* st) {
+  if (!n || !x_in || !params || !wcache || !ctx_v || !scratch || !out || u0 < 1 || u1 <= u0 || u1 > (int)n->units.size())
+    return fail(VLSFR_EINVAL, "vlsfr_mobilenet_forward_units: bad argument");
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  hipStream_t s = (hipStream_t)st;
+  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, s);
+  const Unit& prev = n->units[u0 - 1];
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(ctx + prev.a, x_in, (size_t)n->B * prev.Ho * prev.Wo * prev.d.Cout * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_forward_units: %s", hipGetErrorString(e));
+  for (int k = u0; k < u1; ++k) {
+    if (n->units[k].in_unit < u0 - 1 || (n->units[k].res_unit >= 0 && n->units[k].res_unit < u0 - 1))
+      return fail(VLSFR_EINVAL, "vlsfr_mobilenet_forward_units: unit %d reads a tensor in front of the range", k);
+    RUN(forward_unit(n, k, nullptr, params, running, ctx, wc, st));
   }
+  const Unit& lastu = n->units[u1 - 1];
+  e = hipMemcpyAsync(out, ctx + lastu.a, (size_t)n->B * lastu.Ho * lastu.Wo * lastu.d.Cout * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_forward_units: copy: %s", hipGetErrorString(e));
+  return VLSFR_OK;
+}
+
+int vlsfr_mobilenet_backward_units(const vlsfr_mobilenet* n, int32_t u0, int32_t u1, const void* dout, const float* const* params,
+                                   float* const* grads, const void* wcache, void* ctx_v, void* scratch, void* dx, void* st) {
+  if (!n || !dout || !params || !grads || !wcache || !ctx_v || !scratch || !dx || u0 < 1 || u1 <= u0 || u1 > (int)n->units.size())
+    return fail(VLSFR_EINVAL, "vlsfr_mobilenet_backward_units: bad argument");
+  char* ctx = (char*)ctx_v;
+  const char* wc = (const char*)wcache;
+  Scratch sc = carve(n, scratch);
+  hipStream_t s = (hipStream_t)st;
+  hipError_t e = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, s);
+  const Unit& lastu = n->units[u1 - 1];
+  int cur = 0, pend_unit = -1, pend_buf = -1;
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(sc.g[cur], dout, (size_t)n->B * lastu.Ho * lastu.Wo * lastu.d.Cout * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward_units: %s", hipGetErrorString(e));
+  RUN(backward_units(n, u1 - 1, u0, &cur, &pend_unit, &pend_buf, params, grads, ctx, wc, sc, st));
+  const Unit& prev = n->units[u0 - 1];
+  const int64_t cnt = (int64_t)n->B * prev.Ho * prev.Wo * prev.d.Cout;
+  if (pend_unit == u0 - 1) RUN(vlsfr_add_bf16(sc.g[cur], sc.g[pend_buf], sc.g[cur], cnt, st));   // the range's input also fed its residual add
+  e = hipMemcpyAsync(dx, sc.g[cur], (size_t)cnt * 2, hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward_units: copy: %s", hipGetErrorString(e));
   return VLSFR_OK;
 }
 

@@ -211,7 +211,13 @@ def faces_to_device(raw_list, flips, device):
     transfer each and runs the loader transform on the GPU -> float32 [B, 3, H, W] (vlsfr_faces_normalize)."""
     if torch.device(device).type != "cuda":
         raise _lib.VlsfrError("faces_to_device: the loader transform runs on the GPU; there is no host path")
-    raw = torch.stack([r if torch.is_tensor(r) else torch.from_numpy(np.ascontiguousarray(r)) for r in raw_list])
+    rows = [r if torch.is_tensor(r) else torch.from_numpy(np.ascontiguousarray(r)) for r in raw_list]
+    if len(set(int(r.shape[2]) for r in rows)) > 1:
+        # a batch that mixes grey [H, W, 1] and colour [H, W, 3] records (the reference converts sample by sample,
+        # util/lmdb_loader.py:111-127 / :209-233): grey records take their three equal planes here, which is what the
+        # kernel's C = 1 path writes, so the result is the per-sample conversion's bit for bit
+        rows = [r.expand(r.shape[0], r.shape[1], 3) if r.shape[2] == 1 else r for r in rows]
+    raw = torch.stack(rows)
     B, H, W, C = raw.shape
     raw_d = raw.pin_memory().to(device, non_blocking=True)
     flip_d = torch.as_tensor(np.asarray(flips, dtype=np.uint8)).pin_memory().to(device, non_blocking=True)

@@ -71,6 +71,11 @@ class PoolShadow(object):
             self.version[dtype] = q._version
         return t.data_ptr()
 
+    def invalidate(self):
+        """After a write to the pool that torch's version counter does not see (through `.data`, a raw pointer, an
+        in-place collective on `.data`): the next ptr() rebuilds every mirror."""
+        self.version.clear()
+
     def scatter_target(self):
         """The bf16 mirror's pointer for vlsfr_pool_scatter (which writes the fp32 row and its bf16 image in one launch)."""
         t = self.t.get("bf16")
@@ -279,11 +284,12 @@ class ShardedDcpHead(object):
         self._book = DcpHead.__new__(DcpHead)    # reuse the bookkeeping half
         self._book.L, self._book.lru, self._book.qp = self.L, self.lru, self.qp
         self._ws, self._ws_key = None, None
+        self.n_chunks = int(os.environ.get('VLSFR_HEAD_CHUNKS', 0))     # column partition of the sweep (0 = by size)
 
     def _cfg(self, B):
         fp8 = self.head_dtype == "fp8"
         return HeadCfg(B, self.D, self.Qs, LOSS_TYPES[self.loss_type], self.scale, self.margin, self.hard_neg,
-                       int(self.precise), 0, self.slot_lo, 0, None if fp8 else self.shadow.ptr(not self.precise),
+                       int(self.precise), self.n_chunks, self.slot_lo, 0, None if fp8 else self.shadow.ptr(not self.precise),
                        self.shadow.ptr(not self.precise, "fp8") if fp8 else None)
 
     def begin(self, p_all, g_all, probe_label, gallery_label, transactional):
@@ -294,7 +300,7 @@ class ShardedDcpHead(object):
         dev = p_all.device
         tab_d = torch.from_numpy(tab).pin_memory().to(dev, non_blocking=True)
         cfg = self._cfg(B)
-        key = (B, cfg.pool_bf16, cfg.pool_fp8, cfg.precise, cfg.loss_type, cfg.scale)
+        key = (B, cfg.pool_bf16, cfg.pool_fp8, cfg.precise, cfg.loss_type, cfg.scale, cfg.n_chunks)
         if self._ws_key != key:
             fn = self.L.vlsfr_head_workspace_bytes
             fn.restype, fn.argtypes = ctypes.c_size_t, [ctypes.POINTER(HeadCfg)]

@@ -61,11 +61,14 @@ class SyntheticFaces(object):
             yield inst, inst_label, self._images(h), self._images(h), ids         # + id batch (main.py:43)
 
 
-def save_checkpoint(path, ffc_net, pool, optimizer=None, real_iter=0):
+def save_checkpoint(path, ffc_net, pool, optimizer=None, real_iter=0, allocator=True):
     """The reference's dictionary (main.py:85: state_dict / lru / fc / qp) plus one extra key, `resume`, with what
-    the reference does not save but an exact continuation needs (EMA'd gallery weights, optimizer momenta)."""
-    torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict(),
-                'fc': pool.cpu() if pool is not None else None, 'qp': ffc_net.queue_position_dict.to_dict(),
+    the reference does not save but an exact continuation needs (EMA'd gallery weights, optimizer momenta).
+    allocator=False (shard-wise checkpoints): `lru` and `qp` stay None here — every rank's pool file holds them as
+    arrays (ShardedFFC.pool_state), and a 10 M-entry list of tuples / dict would cost minutes of host serialisation."""
+    torch.save({'state_dict': ffc_net.probe_net.state_dict(), 'lru': ffc_net.lru.state_dict() if allocator else None,
+                'fc': pool.cpu() if pool is not None else None,
+                'qp': ffc_net.queue_position_dict.to_dict() if allocator else None,
                 'resume': {'gallery_state_dict': ffc_net.gallery_net.state_dict(), 'real_iter': int(real_iter),
                            'optimizer': optimizer.state_dict() if optimizer is not None else None}}, path)
 
@@ -101,7 +104,8 @@ def load_checkpoint(path, ffc_net, optimizer=None, step_model=None):
     if optimizer is not None and extra.get('optimizer') is not None:
         optimizer.load_state_dict(extra['optimizer'])
         if hasattr(optimizer, 'scatter_state'):
-            optimizer.scatter_state()
+            optimizer.scatter_state()                    # this rank's 1 / world momentum slices ...
+            optimizer.release_consolidated()             # ... and the full-size buffers go again
     return int(extra.get('real_iter', 0))
 
 
@@ -130,7 +134,8 @@ def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_
         optimizer.step()
         real_iter += 1
         if real_iter % conf.print_freq == 0:                                       # main.py:76-85
-            loss_val = loss.item()
+            # N > 1: every rank holds its own rows' share of the loss; the reference's scalar is their sum (a collective)
+            loss_val = float(step_model.global_loss(loss)) if world > 1 else loss.item()
             lr = optimizer.param_groups[0]['lr']
             log("epoch %d iter %d loss %.4f lr %.5f  %.1f it/s" % (cur_epoch, real_iter, loss_val, lr,
                                                                    conf.print_freq / max(time.time() - start, 1e-9)))
@@ -138,19 +143,24 @@ def train_one_epoch(data, ffc_net, step_model, optimizer, cur_epoch, conf, real_
                 lr_scheduler.step(loss_val)
             start = time.time()
             tag = real_iter // conf.print_freq
-            if hasattr(step_model, 'pool_state'):
-                # sharded pool: every rank writes ITS slots (no rank ever holds the whole pool: 410 GB at 100 M
-                # identities), rank 0 the model / allocator file with fc = None
+            if conf.saved_dir:
+                # the partitioned optimizer's momenta live as 1/N slices: gather them into the per-parameter entries
+                # torch's state_dict() serialises (a collective: every rank, whichever pool form), and let them go again
+                # once the file is written — only when a checkpoint is written at all
                 if hasattr(optimizer, 'consolidate_state'):
-                    optimizer.consolidate_state()                                  # collective
-                if conf.saved_dir:
-                    os.makedirs(conf.saved_dir, exist_ok=True)
+                    optimizer.consolidate_state()
+                os.makedirs(conf.saved_dir, exist_ok=True)
+                if hasattr(step_model, 'pool_state'):
+                    # sharded pool: every rank writes ITS slots and the (replicated) allocator state as arrays (no rank
+                    # ever holds the whole pool: 410 GB at 100 M identities), rank 0 the model file with fc / lru / qp = None
                     torch.save(step_model.pool_state(), os.path.join(conf.saved_dir, '%d.pool%d.pt' % (tag, step_model.rank)))
                     if step_model.rank == 0:
-                        save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % tag), ffc_net, None, optimizer, real_iter)
-            elif conf.saved_dir and (world == 1 or torch.distributed.get_rank() == 0):
-                os.makedirs(conf.saved_dir, exist_ok=True)
-                save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % tag), ffc_net, ffc_net.queue, optimizer, real_iter)
+                        save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % tag), ffc_net, None, optimizer, real_iter,
+                                        allocator=False)
+                elif world == 1 or torch.distributed.get_rank() == 0:
+                    save_checkpoint(os.path.join(conf.saved_dir, '%d.pt' % tag), ffc_net, ffc_net.queue, optimizer, real_iter)
+                if hasattr(optimizer, 'release_consolidated'):
+                    optimizer.release_consolidated()
     return real_iter, loss
 
 

@@ -285,6 +285,12 @@ class PartitionedSGD(FusedSGD):
                 self.state[p]["momentum_buffer"] = torch.as_strided(full, p.shape, p.stride(), storage_offset=o).clone()
                 o += (p.numel() + 3) & ~3
 
+    def release_consolidated(self):
+        """Drops the full-size momentum_buffer entries consolidate_state() left in self.state (the step itself uses the
+        1 / world slices): after a checkpoint has been written the momentum memory is 1 / world per rank again."""
+        for st in self.state.values():
+            st.pop("momentum_buffer", None)
+
     def scatter_state(self):
         """Inverse of consolidate_state (after load_state_dict): this rank's momentum slices from the full buffers."""
         part = self.partition()

@@ -165,6 +165,9 @@ class DataParallelFFC(object):
         pre_sharded = getattr(model, 'pool_shard', None) is not None
         for t in list(model.parameters()) + [b for n, b in model.named_buffers() if not (pre_sharded and n == 'queue')]:
             self.comm.broadcast(t.data)
+        head = getattr(model, "_head", None)
+        if head is not None:                                   # the broadcast wrote the pool through .data (in place under RCCL):
+            head.shadow.invalidate()                           # torch's version counter did not move, the sweep's mirror is stale
         for net in (getattr(model, "probe_net", None),):
             if net is not None:
                 net.__dict__["signal_stages"] = True           # the backward passes record their bucket events
