@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') around two steps")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, identity-sharded pool, "
                     "partitioned SGD, every collective) even with one rank: rehearses the RCCL calls on a 1-GPU box")
+    ap.add_argument("--rehearse-world", type=int, default=0, help="ONE process runs rank 0's step of a W-rank job (shard-local pool "
+                    "of identities / W slots, gathered batch of W x batch rows, replicated LRU, partitioned SGD) with every collective "
+                    "replaced by a local stand-in of the same shape: rank 0's compute at the node's shapes, no wire time "
+                    "(parallel.RehearsalDist).  Config C4: --rehearse-world 8 --identities 104857600 --batch 64")
     ap.add_argument("--head-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the e4m3 sweep of csrc/head8.hip (config C5's "
                     "precision for the class matmul; the backbone stays bf16)")
     ap.add_argument("--phases", action="store_true", help="diagnostic: print the forward / backward / update split to stderr")
@@ -181,8 +185,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    dist_on = world > 1 or args.force_dist        # --force-dist: the N > 1 code path (RCCL collectives included) with one rank
-    if dist_on:
+    rehearse = args.rehearse_world if args.rehearse_world > 1 else 0
+    if rehearse and world != 1:
+        raise SystemExit("--rehearse-world runs in one process")
+    dist_on = world > 1 or args.force_dist or bool(rehearse)   # --force-dist: the N > 1 code path (RCCL collectives included) with one rank
+    if rehearse:
+        from vlsfr_amd.parallel import RehearsalDist
+        dist = RehearsalDist(rehearse, args.identities, seed=99)
+    elif dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -208,11 +218,12 @@ def main():
 
     Q = args.queue or args.identities
     torch.manual_seed(1234)                                   # identical initial weights on every rank
-    sharded = dist_on and args.pool == "sharded" and Q % world == 0
+    pool_world = rehearse or world                             # ranks the pool is split over
+    sharded = dist_on and args.pool == "sharded" and Q % pool_world == 0
     # the pool is drawn straight into HBM in chunks (ffc.build_pool: same normalize(rand) semantics as
     # ffc.py:29-30); under the identity-sharded pool every rank builds only its own slots
     model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, pool_device=dev,
-                pool_shard=(rank, world) if sharded else None).cuda()
+                pool_shard=(rank, pool_world) if sharded else None).cuda()
     model.__dict__['head_dtype'] = args.head_dtype
     if args.serial:
         model.__dict__['concurrent_streams'] = False
@@ -277,6 +288,11 @@ def main():
         note("warm-up step %d done" % i)
     if dist is not None:
         dist.barrier()
+    if rehearse:
+        torch.cuda.synchronize()
+        note("rehearsal of rank 0 of %d: HBM in use %.1f GB (pool shard %.1f GB fp32 + its %s shadow), host RSS %.1f GB" %
+             (rehearse, torch.cuda.memory_allocated() / 1e9, model.queue.numel() * 4 / 1e9, args.head_dtype,
+              __import__("resource").getrusage(__import__("resource").RUSAGE_SELF).ru_maxrss / 1e6))
     if args.sync_debug:
         torch.cuda.set_sync_debug_mode("warn")
         for i in range(2):
@@ -317,7 +333,7 @@ def main():
     note("timed region done: %.3f s for %d steps; GPU ms per step: %s; host-side issue ms per step: %s" %
          (dt, args.steps, " ".join("%.1f" % evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)),
           " ".join("%.1f" % v for v in host_ms)))
-    if dist is not None:
+    if dist is not None and not rehearse:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -396,7 +412,7 @@ def main():
     if hs and hs[2] > 0 and hs[0] > 0:
         # the class matmul north_star singles out: MFMA fraction of both contractions (4 B Q D FLOPs per sweep) and
         # the HBM rate of the pool bytes it streams (bf16 shadow: Q * D * 2 per sweep)
-        pool_bytes = Q // max(world if sharded else 1, 1) * args.feat * 2
+        pool_bytes = Q // max(pool_world if sharded else 1, 1) * args.feat * 2
         (roofline if dom == "head_sweep_kernel" else roofline["other"]["head_sweep_kernel"]).update(
             avg_launch_us=round(hs[0] * 1e3 / hs[2], 1), mfma_frac=round(hs[1] / (hs[0] * 1e-3) / 1e12 / head_peak, 4), mfma_peak=head_peak,
             pool_gb_per_s=round(pool_bytes * hs[2] / (hs[0] * 1e-3) / 1e9, 1))
@@ -423,7 +439,9 @@ def main():
         "config": {"workload": "%s + %d identities, FFC DCP (pool %d slots x %d, loss %s), batch_size %d per GPU "
                                "(2 x %d faces per step per GPU), SGD-nesterov, %dx%d synthetic images" %
                                (args.net, args.identities, Q, args.feat, args.loss, B, B, hw, hw),
-                   "parallelism": ("dp%d" % world) + ("" if not dist_on else "+zero1-sgd+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")),
+                   "parallelism": ("dp%d" % world) + ("" if not dist_on else "+zero1-sgd+pool-" + ("sharded" if isinstance(step_model, ShardedFFC) else "replicated")) +
+                                  ("" if not rehearse else " REHEARSAL: rank 0 of %d in one process, collectives replaced by local stand-ins of the same "
+                                   "shape (no wire time); value = this GPU's faces/sec, gathered batch %d rows, pool shard %d slots" % (rehearse, rehearse * B, Q // rehearse)),
                    "loss": loss_val},
         "roofline": roofline,
     }

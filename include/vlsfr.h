@@ -202,6 +202,33 @@ int vlsfr_head_outlier_accum(const vlsfr_head_cfg* cfg, const float* g, const fl
                              const int32_t* special_col, const int32_t* src1, const int32_t* src2,
                              int32_t n_special, const int32_t* sel_col /*[B,2,k]*/, const float* sel_w /*[B,2,k]*/,
                              int32_t k, float* T /*[B,2,D]*/, void* stream);
+int vlsfr_head_outlier_accum_strided(const vlsfr_head_cfg* cfg, const float* g, const float* queue,
+                                     const int32_t* special_col, const int32_t* src1, const int32_t* src2,
+                                     int32_t n_special, const int32_t* sel_col, const float* sel_w, int32_t k,
+                                     float* T /*row (b, v) at T + (2 b + v) * t_stride*/, int32_t t_stride, void* stream);
+/* The sharded pass as three launches around the ranks' collectives (head.py ShardedDcpHead):
+ *  vlsfr_head_shard_partial_packed — as vlsfr_head_shard_partial(_sv with sv_thr != NULL), but the state goes straight
+ *    into the layout the ranks sum: packed [B, 2, 2 D + 2] = (O[D] | T[D] | L | zt) per row and variant; out_M [B, 2] is the
+ *    exponent the state is relative to.  *fixed_ref = 1: that exponent is the shadow sweep's fixed reference (a function
+ *    of the probe row alone: identical on every rank), so the ranks sum `packed` WITHOUT an all-reduce(max) and without a
+ *    rescale; 0 (fp32-pool sweep): out_M is this rank's maximum, rescale by 2^(M - max over ranks) first.
+ *  vlsfr_head_shard_topk_merge — hard negatives (only when the batch has outlier rows): the global top-hard_neg of the
+ *    gathered candidates [world, B, 2, 10] -> sel_col / sel_w [B, 2, hard_neg] (for vlsfr_head_outlier_accum_strided with
+ *    T = packed + D, t_stride = 2 D + 2) and sel_loss [B, 2].
+ *  vlsfr_head_shard_finish — after the reduce-scatter (or all-reduce) of `packed`: loss share (deterministic sum) and the
+ *    dL/dp rows of the n_rows rows given (their packed rows, exponents Mg [n_rows, 2], labels, sel_loss or NULL);
+ *    row_loss: scratch [n_rows, 2]. */
+int vlsfr_head_shard_partial_packed(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                                    const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                                    const int32_t* src2, int32_t n_special, int32_t n_pos, const float* sv_thr /*or NULL*/,
+                                    float* packed, float* out_M, float* cand_val, int32_t* cand_col, int32_t* fixed_ref,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+int vlsfr_head_shard_topk_merge(const vlsfr_head_cfg* cfg, const float* cand_val, const int32_t* cand_col, int32_t world,
+                                const int32_t* pool_label, int32_t n_out, int32_t* sel_col, float* sel_w, float* sel_loss,
+                                void* stream);
+int vlsfr_head_shard_finish(const vlsfr_head_cfg* cfg, const float* packed, const float* Mg, const int32_t* pool_label,
+                            const float* sel_loss, int32_t n_rows, int32_t n_pos, float* row_loss, float* loss_out, float* dP,
+                            void* stream);
 int vlsfr_head_fwd_bwd(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
                        const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
                        const int32_t* src2, int32_t n_special, int32_t n_pos, float* loss_out, float* dP,
@@ -236,6 +263,23 @@ typedef struct vlsfr_conv_desc {
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk,
                      int32_t out_f32, float* stats, void* stream);
 int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream);
+/* The same with the reduction of the BatchNorm (+ PReLU) backward that consumes dx as ITS dY fused into the epilogue
+ * (resnet_arcface.py:35-38 backward: bn1 behind conv1, bn2 + prelu behind conv2): x is that layer's input (bf16, shape of
+ * dx), mean / invstd its saved batch statistics, gamma / beta / slope its parameters (slope NULL: plain BatchNorm; gamma /
+ * beta are then not read), red its fp32 [VLSFR_BN_REPL][3][Cin] accumulators (pre-zeroed): sum dz, sum dz * xhat,
+ * sum dy * min(z, 0) with z = bn(x), dz = dy * prelu'(z), from the ROUNDED dx.  The later vlsfr_bn_backward_chain call for
+ * that layer passes red_ready = 1.  bn == NULL: plain vlsfr_conv2d_dgrad. */
+typedef struct vlsfr_bn_red {
+  const void* x;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  const float* slope;
+  float* red;
+} vlsfr_bn_red;
+int vlsfr_conv2d_dgrad_bnred(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, const vlsfr_bn_red* bn,
+                             void* stream);
 /* splitk <= 0: library choice */
 int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
                        void* stream);
@@ -304,6 +348,11 @@ int vlsfr_bn_backward_chain(const void* dy, const void* x, void* dx, int64_t M, 
                             const void* dx_add, float* dgamma, float* dbeta, float* dslope, int32_t dy_nchw,
                             int32_t red_ready, const void* next_x, const float* next_mean, const float* next_invstd,
                             float* next_red, void* stream);
+/* Only the reduction of vlsfr_bn_backward (red [VLSFR_BN_REPL][3][C], pre-zeroed: sum dz, sum dz * xhat, sum dy * min(z, 0));
+ * what vlsfr_conv2d_dgrad_bnred falls back to when a launch carries no fused epilogue. */
+int vlsfr_bn_backward_reduce(const void* dy, const void* x, int64_t M, int32_t C, int32_t HW, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
+                             void* stream);
 int vlsfr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
 /* e = normalize(bn1d(fc + fc_bias)); all fp32 [B, D] */
 int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, const float* beta,

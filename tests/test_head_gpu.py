@@ -252,8 +252,9 @@ def _sharded_pass(shards, p, g, pl, gl, trans):
     total = torch.stack([c.mine for c in comms]).sum(0)
     outs = []
     for r, h in enumerate(shards):
-        sts[r]["packed"] = total.clone()
-        outs.append(h.finish(sts[r]))
+        sts[r]["summed"] = total.clone()
+        l, dP = h.finish(sts[r])
+        outs.append((l.clone(), dP))
     return outs
 
 
@@ -654,7 +655,8 @@ def test_c4_rank0_shard_of_a_100m_identity_pool():
             loss, dP = head.finish(st)
             e1.record()
             torch.cuda.synchronize()
-            outs.append((float(loss), dP.cpu().numpy(), st["M"].cpu().numpy(), st["L"].cpu().numpy()))
+            outs.append((float(loss), dP.cpu().numpy(), st["M"].cpu().numpy(), head.unpack(st)["L"].cpu().numpy()))
+            assert st["fixed_ref"]                           # the shadow sweeps need no all-reduce(max)
             print("C4 rank-0 shard, %s sweep, n_chunks %d: %.2f ms per pass (%d gathered rows x %d slots)" %
                   (dtype, n_chunks, e0.elapsed_time(e1), Bg, Qs))
         # (1) rollback: nothing moved

@@ -460,3 +460,71 @@ def test_wgrad_slab_path_is_deterministic_and_matches_atomics(cin, cout, k, stri
         assert torch.equal(a, b)                                # deterministic
     c, _ = ops.conv2d_wgrad_ws(dy, x, d, dw=a.clone())
     close(c, (2 * ref).cpu(), 1e-4)
+
+
+# (cin, cout, stride, hw, N, prelu): conv1 -> bn1 (plain) and conv2 -> bn2 + PReLU of an IBasicBlock backward, on the 128 x 128
+# and the 64 x 128 tile, stride 2 (four parity-class launches accumulate into one reduction), a pixel count that is not a
+# multiple of the tile (ragged last tile), and the 1 x 1 stride-2 shortcut (the rows the launch does not visit are zero)
+BNRED_CASES = [(256, 256, 1, 14, 8, True), (256, 256, 1, 14, 8, False), (64, 64, 1, 28, 3, True), (128, 128, 2, 28, 4, True),
+               (64, 64, 2, 56, 2, False), (128, 256, 1, 7, 5, True), (512, 512, 1, 7, 3, False)]
+
+
+@pytest.mark.parametrize("cin,cout,stride,hw,N,prelu", BNRED_CASES)
+def test_dgrad_epilogue_accumulates_the_batchnorm_backward_reduction(cin, cout, stride, hw, N, prelu, conv_variant):
+    """vlsfr_conv2d_dgrad_bnred: the input gradient is the plain dgrad's bit for bit, and the reduction its epilogue
+    accumulated (sum dz, sum dz * xhat, sum dy * min(z, 0) over the ROUNDED gradient) equals the stand-alone reduction kernel
+    run on that gradient (same arithmetic, other summation order: 1e-4 of the per-channel scale) and a float64 evaluation.
+    Every conv variant: the ones without the fused epilogue take the stand-alone kernel inside the call."""
+    from vlsfr_amd import ops
+    torch.manual_seed(cin + cout + hw)
+    d = ops.ConvDesc(N, hw, hw, cin, cout, 3, 3, stride, 1)
+    Ho = ops.out_hw(hw, 3, stride, 1)
+    w = torch.randn(cout, 3, 3, cin, device="cuda") / np.sqrt(9 * cin)
+    _, wT = ops.cast_weight(w, cout, 9, cin)
+    dy = (torch.randn(N, Ho, Ho, cout, device="cuda") * 0.05).to(torch.bfloat16)
+    x = (torch.randn(N, hw, hw, cin, device="cuda") * (0.5 + torch.rand(cin, device="cuda")) + torch.randn(cin, device="cuda")).to(torch.bfloat16)
+    M = N * hw * hw
+    xf = x.float().reshape(M, cin)
+    mean = xf.mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).contiguous()
+    gamma = (1.0 + 0.2 * torch.randn(cin, device="cuda")).contiguous()
+    beta = (0.3 * torch.randn(cin, device="cuda")).contiguous()
+    slope = (0.25 + 0.05 * torch.randn(cin, device="cuda")).contiguous() if prelu else None
+    plain = ops.conv2d_dgrad(dy, wT, d)
+    dx, red = ops.conv2d_dgrad_bnred(dy, wT, d, x, mean, invstd, gamma, beta, slope)
+    assert torch.equal(dx, plain)
+    ref = ops.bn_backward_reduce(dx, x, M, cin, hw * hw, mean, invstd, gamma, beta, slope)
+    torch.cuda.synchronize()
+    got, want = red.double().sum(0).cpu().numpy(), ref.double().sum(0).cpu().numpy()
+    # float64 evaluation from the rounded gradient
+    g64, x64 = dx.double().reshape(M, cin), x.double().reshape(M, cin)
+    xhat = (x64 - mean.double()) * invstd.double()
+    z = xhat * gamma.double() + beta.double()
+    dz = torch.where(z <= 0, g64 * slope.double(), g64) if prelu else g64
+    exact = torch.stack([dz.sum(0), (dz * xhat).sum(0), torch.where(z <= 0, g64 * z, torch.zeros_like(z)).sum(0) if prelu
+                         else torch.zeros(cin, dtype=torch.float64, device="cuda")]).cpu().numpy()
+    scale = np.abs(exact).max(axis=1, keepdims=True) + 1e-12
+    np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)
+    np.testing.assert_allclose(got / scale, exact / scale, atol=2e-4)
+
+
+def test_dgrad_bnred_1x1_stride2_shortcut():
+    """The 1 x 1 stride-2 shortcut's input gradient is zero at the odd positions (one parity-class launch over a memset
+    tensor): the fused reduction of that launch is the whole reduction."""
+    from vlsfr_amd import ops
+    torch.manual_seed(3)
+    N, hw, cin, cout = 4, 28, 128, 256
+    d = ops.ConvDesc(N, hw, hw, cin, cout, 1, 1, 2, 0)
+    w = torch.randn(cout, 1, 1, cin, device="cuda") / np.sqrt(cin)
+    _, wT = ops.cast_weight(w, cout, 1, cin)
+    dy = (torch.randn(N, hw // 2, hw // 2, cout, device="cuda") * 0.05).to(torch.bfloat16)
+    x = torch.randn(N, hw, hw, cin, device="cuda").to(torch.bfloat16)
+    M = N * hw * hw
+    mean = x.float().reshape(M, cin).mean(0).contiguous()
+    invstd = (1.0 / torch.sqrt(x.float().reshape(M, cin).var(0, unbiased=False) + 1e-5)).contiguous()
+    dx, red = ops.conv2d_dgrad_bnred(dy, wT, d, x, mean, invstd)
+    assert torch.equal(dx, ops.conv2d_dgrad(dy, wT, d))
+    ref = ops.bn_backward_reduce(dx, x, M, cin, hw * hw, mean, invstd)
+    got, want = red.double().sum(0).cpu().numpy(), ref.double().sum(0).cpu().numpy()
+    scale = np.abs(want).max(axis=1, keepdims=True) + 1e-12
+    np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)

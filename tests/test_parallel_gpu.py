@@ -208,8 +208,8 @@ def test_two_rank_training_driver_checkpoints_and_resumes(tmp_path, pool):
         assert res[0]["files"] == ["1.pt", "2.pt"]
         assert ck["fc"].shape == (2, 64, 32) and len(ck["qp"]) == 64
     mom = [v.get("momentum_buffer") for v in ck["resume"]["optimizer"]["state"].values()]
-    assert len(mom) > 10 and all(m is not None and float(m.abs().max()) > 0 for m in mom)     # the momenta are IN the file
-    w_ck = ck["state_dict"]["layer1.0.conv1.weight"].float().numpy()
+    assert len(mom) > 10 and all(m is not None and float(m.float().abs().max()) > 0 for m in mom)     # the momenta are IN the file
+    w_ck = ck["state_dict"]["layer1.0.conv1.weight"].float().cpu().numpy()
     rel = lambda u, v: float(np.linalg.norm(u - v) / (np.linalg.norm(v) + 1e-30))
     for r in range(WORLD):
         a, b = res[r]["a"], res[r]["b"]

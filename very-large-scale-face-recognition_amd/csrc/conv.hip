@@ -54,6 +54,7 @@ ProfScope::~ProfScope() {
 extern int g_dw_wgrad_blocks;   // csrc/dw.hip
 extern int g_dw_strip;          // csrc/dw.hip
 extern int g_bn_chain;          // csrc/iresnet.cpp
+extern int g_dgrad_bnred;       // csrc/iresnet.cpp
 int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
 
@@ -101,6 +102,17 @@ struct ConvArgs {
   unsigned long long tap_w = 0;   // 4 bits per virtual tap: the tap of the weight matrix it multiplies
   int cls = 0;                    // 0: dense output rows p; 1 + 2 ph + pw: row of pixel (n, h', w') = (n Hf + 2 h' + ph) Wf + 2 w' + pw
   int Hf = 0, Wf = 0;
+  // Input-gradient launches whose output is the dY of a BatchNorm (+ PReLU) backward (vlsfr_conv2d_dgrad_bnred): the epilogue
+  // holds the tile of dY it has just rounded, reads the matching tile of that layer's input x once, and accumulates the
+  // layer's reduction (sum dz, sum dz * xhat, sum dy * min(z, 0); norm.hip bn_bwd_reduce_kernel) — that kernel, which read
+  // dY and x again from HBM, is no longer launched.
+  const u16* red_x = nullptr;     // [rows of y][Mrows] bf16
+  const float* red_mean = nullptr;
+  const float* red_invstd = nullptr;
+  const float* red_gamma = nullptr;
+  const float* red_beta = nullptr;
+  const float* red_slope = nullptr;   // PReLU slopes or nullptr (plain BatchNorm)
+  float* red_out = nullptr;       // [VLSFR_BN_REPL][3][Mrows], pre-zeroed
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (id % 8), and each XCD has its own L2.  This maps
@@ -123,7 +135,7 @@ __device__ __forceinline__ int swz(int row) {
   else return row & 7;
 }
 
-template <int BM, int BN, int WM, int WN, int MT, int NT, int NW>
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
                                               int r16, int h, int tid, float* red_lds);
 
@@ -301,7 +313,7 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
 // Shared epilogue of the LDS-DMA convolution kernels: lane (r16, h) of wave (wm, wn) holds channels
 // m0 + wm*(BM/WM) + 16 i + 4h + e of pixels p0 + wn*(BN/WN) + 16 j + r16.  fp32 output (plain or split-K
 // atomics) or bf16 output with the fused BatchNorm statistics; red_lds = BM*WN*2 floats of LDS nobody reads.
-template <int BM, int BN, int WM, int WN, int MT, int NT, int NW>
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
                                               int r16, int h, int tid, float* red_lds) {
   // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
@@ -400,50 +412,138 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
       }
     }
   };
-  if (p0 + BN <= P && m0 + BM <= a.Mrows) store(std::true_type{});
-  else store(std::false_type{});
-  if (a.stats) {
-    // fused BatchNorm statistics: the 16 pixel lanes of a row are summed with DPP adds (no LDS
-    // round trips), lane r16 of row h keeps channel 16 (r16 >> 2) + 4h + (r16 & 3); the WN pixel
-    // halves of the workgroup meet in the LDS stage the last k-tile did not use (its readers all
-    // passed the last barrier), then ONE global atomic per channel and workgroup.
-    float* red = red_lds;   // [WN][2][BM]
-    constexpr int NR = (MT + 3) / 4;   // rounds of 16 (i, e) values: one value per pixel lane of the row
-    float sv[NR], qv[NR];
+  const bool full_tile = p0 + BN <= P && m0 + BM <= a.Mrows;
+  // BatchNorm-backward reduction fused into an input-gradient launch (RED; ConvArgs::red_x): the x tile is fetched with the
+  // store's own addresses (16 bytes per lane), one 16-channel row block (i) ahead of the arithmetic; the first block is
+  // requested BEFORE the stores are issued, so its latency runs under them
+  constexpr int NXQ = RED ? NT / 2 : 1;
+  uint4 xa[NXQ], xb[NXQ];
+  auto loadx = [&](int i, uint4 (&dst)[NXQ]) {
+    if constexpr (RED) {
+      const u16* xbase = a.red_x + (mw - 4 * (h & 1));
 #pragma unroll
-    for (int r = 0; r < NR; ++r) sv[r] = qv[r] = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float s = row16_sum(cs[i][e]), q = row16_sum(cq[i][e]);
-        if (r16 == (i & 3) * 4 + e) {
-          sv[i >> 2] = s;
-          qv[i >> 2] = q;
-        }
+      for (int jp = 0; jp < NT / 2; ++jp) {
+        const int j = 2 * jp + (odd ? 1 : 0);
+        const bool ok = full_tile || (pw + j * 16 < P && mw - 4 * (h & 1) + i * 16 < a.Mrows);
+        dst[jp] = ok ? *(const uint4*)(xbase + (size_t)orow[jp] * a.Mrows + i * 16) : make_uint4(0, 0, 0, 0);
       }
+    }
+  };
+  loadx(0, xa);
+  if (full_tile) store(std::true_type{});
+  else store(std::false_type{});
+  // Per-channel sums -> one of VLSFR_BN_REPL replicated accumulators out[rep][q][Mrows].  A lane's partial for channel
+  // 16 i + 4 h + e (of this wave's channel range) is summed over the 16 pixel lanes of its row with DPP adds (no LDS round
+  // trips) and kept by lane r16 = 4 (i & 3) + e; the WN pixel halves of the workgroup meet in the LDS stage the last k-tile
+  // did not use (its readers all passed the last barrier), then ONE global atomic per channel, quantity and workgroup.
+  constexpr int NR = (MT + 3) / 4;   // rounds of 16 (i, e) values: one value per pixel lane of the row
+  auto fold = [&](float t, int i, int e, float (&keep)[NR]) {
+    t = row16_sum(t);
+    if (r16 == (i & 3) * 4 + e) keep[i >> 2] = t;
+  };
+  auto flush = [&](auto nq_tag, float (&keep)[decltype(nq_tag)::value][NR], float* out) {
+    constexpr int NQ = decltype(nq_tag)::value;
+    float* red = red_lds;   // [WN][NQ][BM]
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const int ni = MT - 4 * r < 4 ? MT - 4 * r : 4;
       if (r16 < ni * 4) {
         const int ml = wm * (BM / WM) + (4 * r + (r16 >> 2)) * 16 + 4 * h + (r16 & 3);
-        red[(wn * 2 + 0) * BM + ml] = sv[r];
-        red[(wn * 2 + 1) * BM + ml] = qv[r];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) red[(wn * NQ + q) * BM + ml] = keep[q][r];
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % VLSFR_BN_REPL) * 2 * a.Mrows;
-    for (int i = tid; i < 2 * BM; i += NW * 64) {
+    float* dst = out + (size_t)(blockIdx.x % VLSFR_BN_REPL) * NQ * a.Mrows;
+    for (int i = tid; i < NQ * BM; i += NW * 64) {
       const int k = i / BM, ml = i - k * BM;
-      float v = 0.f;
+      float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < WN; ++w) v += red[(w * 2 + k) * BM + ml];
-      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, v);
+      for (int w = 0; w < WN; ++w) t += red[(w * NQ + k) * BM + ml];
+      if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, t);
     }
+  };
+  if (a.stats) {   // fused BatchNorm statistics of the rounded output (forward launches)
+    float keep[2][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        fold(cs[i][e], i, e, keep[0]);
+        fold(cq[i][e], i, e, keep[1]);
+      }
+    flush(std::integral_constant<int, 2>{}, keep, a.stats);
+  }
+  if constexpr (RED) {
+    // dz = dy * prelu'(z), z = bn(x) = x * zs + zo; sums of dz, dz * (x - mean) (times invstd = dz * xhat) and, for the
+    // PReLU slope gradient, dy * z over z <= 0 — from the ROUNDED dy (what the BatchNorm backward reads back)
+    const bool prelu = a.red_slope != nullptr;
+    float keep[3][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = keep[2][r] = 0.f;
+    static_for<MT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      uint4(&cur)[NXQ] = (i & 1) ? xb : xa;
+      uint4(&nxt)[NXQ] = (i & 1) ? xa : xb;
+      if constexpr (i + 1 < MT) loadx(i + 1, nxt);
+      const int mc = mw + i * 16;
+      const bool mok = mc < a.Mrows;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+      const f32x4 c_mean = mok ? *(const f32x4*)(a.red_mean + mc) : zero4;
+      const f32x4 c_is = mok ? *(const f32x4*)(a.red_invstd + mc) : zero4;
+      f32x4 zs = one4, zo = zero4, sl = one4;
+      if (prelu && mok) {
+        const f32x4 g = a.red_gamma ? *(const f32x4*)(a.red_gamma + mc) : one4;
+        const f32x4 b = a.red_beta ? *(const f32x4*)(a.red_beta + mc) : zero4;
+        sl = *(const f32x4*)(a.red_slope + mc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          zs[e] = c_is[e] * g[e];
+          zo[e] = b[e] - c_mean[e] * zs[e];
+        }
+      }
+      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jp = 0; jp < NT / 2; ++jp) {
+        // undo the store's lane exchange: after the swaps dword k of pixel tile 2 jp + t is xt[t][k] on every lane
+        const auto t0 = __builtin_amdgcn_permlane16_swap(cur[jp].x, cur[jp].z, false, false);
+        const auto t1 = __builtin_amdgcn_permlane16_swap(cur[jp].y, cur[jp].w, false, false);
+        const uint32_t xt[2][2] = {{t0[0], t1[0]}, {t0[1], t1[1]}};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int j = 2 * jp + t;
+          const bool ok = full_tile || (pw + j * 16 < P && mok);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t wd = xt[t][e >> 1];
+            const float xf = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+            const float dyv = ok ? (float)(__bf16)acc[i][j][e] : 0.f;
+            float dz = dyv;
+            if (prelu) {
+              const float z = xf * zs[e] + zo[e];
+              const bool neg = z <= 0.f;
+              s2[e] += neg ? dyv * z : 0.f;
+              dz = neg ? dyv * sl[e] : dyv;
+            }
+            s0[e] += dz;
+            s1[e] += dz * (xf - c_mean[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        fold(s0[e], i, e, keep[0]);
+        fold(s1[e] * c_is[e], i, e, keep[1]);
+        fold(s2[e], i, e, keep[2]);
+      }
+    });
+    flush(std::integral_constant<int, 3>{}, keep, a.red_out);
   }
 }
 
-template <int BM, int BN, int BK, int NST, int NW, bool PP = false, bool SWP = false>
+template <int BM, int BN, int BK, int NST, int NW, bool PP = false, bool SWP = false, bool RED = false>
 __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW == 8 && BM * BN <= 128 * 128) || SWP) ? 2 : 1) void conv_igemm_glds_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-descriptor builtins exist in the device pass only
   // wave grid WM x WN (NW waves): each wave keeps (BM / WM) x (BN / WN) of the tile; the 8-wave
@@ -771,7 +871,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  conv_epilogue<BM, BN, WM, WN, MT, NT, NW>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)(smem + (nk % NST) * STAGE));
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, RED>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)(smem + (nk % NST) * STAGE));
 #endif
 }
 
@@ -1405,11 +1505,11 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
 }
 
 
-template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false, bool SWP = false>
+template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false, bool SWP = false, bool RED = false>
 int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
   static bool attr_set = false;
-  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW, PP, SWP>;
+  auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW, PP, SWP, RED>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return hip_fail(e, "conv_igemm_glds: hipFuncSetAttribute");
@@ -1450,9 +1550,12 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
   else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32>), grid, dim3(256), 0, st, a);
 }
 
-int run_igemm(ConvArgs a, hipStream_t st) {
+// red_done (optional): set to whether this launch accumulated the BatchNorm-backward reduction of ConvArgs::red_x (only the
+// default LDS-DMA tiles carry the RED epilogue; the caller runs the stand-alone reduction otherwise)
+int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   const int P = a.Nimg * a.Ho * a.Wo;
   a.trace = g_conv_trace;
+  if (red_done) *red_done = false;
   // ALGORITHMIC FLOPs of the convolution this launch implements (what bench.py's roofline may count):
   // the input gradient of a stride-2 layer visits every INPUT position, but 3/4 of its taps are the
   // zero rows of the dilated dY, so it is priced at the forward's output positions (= the positions of
@@ -1513,13 +1616,23 @@ int run_igemm(ConvArgs a, hipStream_t st) {
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
-    else rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
+    else if (a.red_x && !a.out_f32 && a.splitk == 1) {
+      rc = big ? launch_igemm_glds<128, 128, 64, 2, 4, false, false, true>(a, P, st)
+               : launch_igemm_glds<64, 128, 64, 2, 4, false, false, true>(a, P, st);
+      if (red_done) *red_done = true;
+    } else rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     if (rc != VLSFR_OK) return rc;
   } else if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);
   else if (a.Mrows >= 128) launch_igemm<128, 64>(a, P, st);
   else launch_igemm<64, 128>(a, P, st);
   VLSFR_HIP_CHECK_LAUNCH("conv_igemm launch");
   return VLSFR_OK;
+}
+
+// the stand-alone reduction for launches that carried no RED epilogue (register-staged / halo / A-B tile variants)
+int bn_red_fallback(const vlsfr_conv_desc* d, const void* dx, const vlsfr_bn_red* bn, void* stream) {
+  return vlsfr_bn_backward_reduce(dx, bn->x, (int64_t)d->N * d->H * d->W, d->Cin, d->H * d->W, bn->mean, bn->invstd, bn->gamma,
+                                  bn->beta, bn->slope, bn->red, stream);
 }
 
 }  // namespace
@@ -1579,6 +1692,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "bn_chain")) {
     vlsfr::g_bn_chain = value != 0;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "dgrad_bnred")) {
+    vlsfr::g_dgrad_bnred = value != 0;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "dw_strip")) {
@@ -1690,11 +1807,27 @@ int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, voi
 }
 
 int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream) {
+  return vlsfr_conv2d_dgrad_bnred(d, dy, wT, dx, nullptr, stream);
+}
+
+int vlsfr_conv2d_dgrad_bnred(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, const vlsfr_bn_red* bn,
+                             void* stream) {
   int rc = conv_check(d, "vlsfr_conv2d_dgrad");
   if (rc) return rc;
   if (!dy || !wT || !dx) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad: null buffer");
   if (d->Cout % 32 != 0) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad: Cout must be a multiple of 32");
+  if (bn && (!bn->x || !bn->mean || !bn->invstd || !bn->red || d->Cin % 8))
+    return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad_bnred: x, mean, invstd and red are required (Cin %% 8 == 0)");
   ConvArgs a;
+  if (bn) {
+    a.red_x = (const u16*)bn->x;
+    a.red_mean = bn->mean;
+    a.red_invstd = bn->invstd;
+    a.red_gamma = bn->gamma;
+    a.red_beta = bn->beta;
+    a.red_slope = bn->slope;
+    a.red_out = bn->red;
+  }
   a.x = (const u16*)dy;
   a.w = (const u16*)wT;
   a.y = dx;
@@ -1733,8 +1866,12 @@ int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT,
       a.tap_mask = 1u;
       a.tap_w = 0;
       a.cls = 1;
-      return run_igemm(a, st);
+      bool done = false;     // zero rows add nothing to any of the three sums: the class launch's share is the whole reduction
+      rc = run_igemm(a, st, &done);
+      if (rc || !bn || done) return rc;
+      return bn_red_fallback(d, dx, bn, stream);
     }
+    bool all_done = true;
     for (int ph = 0; ph < 2; ++ph)
       for (int pw = 0; pw < 2; ++pw) {
         // virtual tap r' (row offset r' - 1 on the dY grid) <-> filter tap r:  ph = 0: r' = 1 <-> r = 1;
@@ -1751,12 +1888,21 @@ int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT,
             a.tap_w |= (unsigned long long)(rf * 3 + sf) << (4 * (rv * 3 + sv));
           }
         a.cls = 1 + 2 * ph + pw;
-        rc = run_igemm(a, st);
+        bool done = false;
+        rc = run_igemm(a, st, &done);
         if (rc) return rc;
+        all_done = all_done && done;
       }
+    if (bn && !all_done) {
+      if (g_use_glds == VLSFR_DEFAULT_CONV_VARIANT) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad_bnred: parity-class launches disagree");
+      return bn_red_fallback(d, dx, bn, stream);   // A/B tile variants carry no RED epilogue: none of the four accumulated
+    }
     return VLSFR_OK;
   }
-  return run_igemm(a, (hipStream_t)stream);
+  bool done = false;
+  rc = run_igemm(a, (hipStream_t)stream, &done);
+  if (rc || !bn || done) return rc;
+  return bn_red_fallback(d, dx, bn, stream);
 }
 
 size_t vlsfr_conv2d_wgrad_workspace_bytes(const vlsfr_conv_desc* d, int32_t splitk) {

@@ -726,6 +726,11 @@ struct ShardFinishArgs {
   float* cand_val;     // [B, 2, KTOP]
   int32_t* cand_col;   // [B, 2, KTOP] global slot ids (-1 = none)
   const float* sv_thr; // SV: [2][Bp] GLOBAL hard-example thresholds gt - margin (max over ranks), else nullptr
+  float* packed;       // or nullptr.  [B, 2, 2 D + 2] rows (O | T | L | zt): the layout the ranks sum (reduce-scatter), written
+                       // here directly instead of out_O / out_T / out_L / out_zt
+  int fixed_ref;       // 1: the shadow sweep ran (every chunk's part_m is the row's fixed reference exponent, a function of
+                       // the probe row only and so identical on every rank): the state is emitted relative to it, not to
+                       // this rank's maximum, and the ranks need no all-reduce(max) before they sum
 };
 
 __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs sa) {
@@ -820,7 +825,10 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       }
       float mx = NEG_BIG;
       for (int c = tid; c < a.n_chunks; c += 256) mx = fmaxf(mx, a.part_m[v][(size_t)c * a.Bp + i]);
-      for (int k = tid; k < n_own; k += 256) mx = fmaxf(mx, cmod(own[k]) * qs);
+      // fixed_ref: the special columns stay out of the maximum — their terms 2^(z - m_ref) are below 2^60 by the sweep's
+      // own bound (head16.hip: m_ref = largest possible logit - 60)
+      if (!sa.fixed_ref)
+        for (int k = tid; k < n_own; k += 256) mx = fmaxf(mx, cmod(own[k]) * qs);
       const float M = block_max(mx);
       float lsum = 0.f;
       for (int c = tid; c < a.n_chunks; c += 256) {
@@ -830,8 +838,8 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       }
       for (int k = tid; k < n_own; k += 256) lsum += exp2f(cmod(own[k]) * qs - M);
       const float L = block_sum(lsum);
-      float* O = sa.out_O + ((size_t)i * 2 + v) * D;
-      float* T = sa.out_T + ((size_t)i * 2 + v) * D;
+      float* O = sa.packed ? sa.packed + ((size_t)i * 2 + v) * (2 * D + 2) : sa.out_O + ((size_t)i * 2 + v) * D;
+      float* T = sa.packed ? O + D : sa.out_T + ((size_t)i * 2 + v) * D;
       combine_strided(a.part_o[v] + (size_t)i * a.DP, (size_t)a.Bp * a.DP, wts, a.n_chunks, D, wsum);
       for (int d = tid; d < D; d += 256) {
         O[d] = (wsum[d] + wsum[D + d]) + (wsum[2 * D + d] + wsum[3 * D + d]);
@@ -854,8 +862,14 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
       }
       if (tid == 0) {
         sa.out_M[i * 2 + v] = M;
-        sa.out_L[i * 2 + v] = L;
-        sa.out_zt[i * 2 + v] = st >= 0 ? tm * a.scale : 0.f;
+        const float ztv = st >= 0 ? tm * a.scale : 0.f;
+        if (sa.packed) {
+          O[2 * D] = L;
+          O[2 * D + 1] = ztv;
+        } else {
+          sa.out_L[i * 2 + v] = L;
+          sa.out_zt[i * 2 + v] = ztv;
+        }
       }
       __syncthreads();
     }
@@ -922,14 +936,20 @@ __global__ __launch_bounds__(256) void head_finish_shard_kernel(ShardFinishArgs 
           last_v = NEG_BIG;   // exhausted: the remaining entries stay empty
         }
       }
-      for (int d = tid; d < D; d += 256) {
-        sa.out_O[((size_t)i * 2 + v) * D + d] = 0.f;
-        sa.out_T[((size_t)i * 2 + v) * D + d] = 0.f;
-      }
-      if (tid == 0) {
-        sa.out_M[i * 2 + v] = NEG_BIG;
-        sa.out_L[i * 2 + v] = 0.f;
-        sa.out_zt[i * 2 + v] = 0.f;
+      if (sa.packed) {
+        float* row = sa.packed + ((size_t)i * 2 + v) * (2 * D + 2);
+        for (int d = tid; d < 2 * D + 2; d += 256) row[d] = 0.f;
+        if (tid == 0) sa.out_M[i * 2 + v] = NEG_BIG;
+      } else {
+        for (int d = tid; d < D; d += 256) {
+          sa.out_O[((size_t)i * 2 + v) * D + d] = 0.f;
+          sa.out_T[((size_t)i * 2 + v) * D + d] = 0.f;
+        }
+        if (tid == 0) {
+          sa.out_M[i * 2 + v] = NEG_BIG;
+          sa.out_L[i * 2 + v] = 0.f;
+          sa.out_zt[i * 2 + v] = 0.f;
+        }
       }
     }
   }
@@ -941,7 +961,7 @@ __global__ __launch_bounds__(256) void head_outlier_accum_kernel(const float* g,
                                                                  int slot_lo, const int32_t* special_col,
                                                                  const int32_t* src1, const int32_t* src2,
                                                                  int n_special, const int32_t* sel_col,
-                                                                 const float* sel_w, int k, float* T) {
+                                                                 const float* sel_w, int k, float* T, int tstride) {
   const int row = blockIdx.x, v = blockIdx.y;
   for (int e = 0; e < k; ++e) {
     const int col = sel_col[((size_t)row * 2 + v) * k + e];
@@ -954,7 +974,74 @@ __global__ __launch_bounds__(256) void head_outlier_accum_kernel(const float* g,
         break;
       }
     const float* vec = special_vec(g, queue, Q, D, col - slot_lo, src);
-    for (int d = threadIdx.x; d < D; d += 256) T[((size_t)row * 2 + v) * D + d] += w * vec[d];
+    for (int d = threadIdx.x; d < D; d += 256) T[((size_t)row * 2 + v) * tstride + d] += w * vec[d];
+  }
+}
+
+// Global top-k of the hard-negative candidates of every outlier row (ffc.py:86-90 over the identity-sharded pool): each
+// rank contributed its local top-KTOP (value, global slot) per row and variant; one thread per (row, variant) picks the k
+// best of the W * KTOP gathered candidates (value descending, slot ascending on ties: every rank selects the same set),
+// clips at zero (ffc.py:89) and emits the weights 1 / (n_out k) of the kept ones and the row's loss term.
+__global__ __launch_bounds__(256) void head_topk_merge_kernel(const float* cand_val, const int32_t* cand_col, int W, int B, int k,
+                                                              const int32_t* pool_label, float inv, int32_t* sel_col,
+                                                              float* sel_w, float* sel_loss) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * B) return;
+  const int row = idx >> 1;
+  const bool is_out = pool_label[row] < 0;
+  float last_v = 3.0e38f;
+  int last_c = -1;
+  float loss = 0.f;
+  for (int e = 0; e < k; ++e) {
+    float bv = NEG_BIG;
+    int bc = 0x7fffffff;
+    if (is_out)
+      for (int w = 0; w < W; ++w)
+        for (int j = 0; j < KTOP; ++j) {
+          const size_t o = ((size_t)w * B * 2 + idx) * KTOP + j;
+          const float cv = cand_val[o];
+          const int cc = cand_col[o];
+          if (cv <= NEG_BIG || cc < 0) continue;
+          if (!((cv < last_v) || (cv == last_v && cc > last_c))) continue;   // already taken
+          if (cv > bv || (cv == bv && cc < bc)) {
+            bv = cv;
+            bc = cc;
+          }
+        }
+    const bool have = bv > NEG_BIG;
+    const bool keep = have && bv >= 0.f;                  // clip(min = 0): negative cosines contribute nothing
+    sel_col[(size_t)idx * k + e] = have ? bc : -1;
+    sel_w[(size_t)idx * k + e] = keep ? inv : 0.f;
+    if (keep) loss += bv;
+    if (have) {
+      last_v = bv;
+      last_c = bc;
+    } else {
+      last_v = NEG_BIG;
+    }
+  }
+  sel_loss[idx] = loss * inv;
+}
+
+// Loss terms and dL/dp rows from the summed state of the identity-sharded head: packed [n, 2, 2 D + 2] (O | T | L | zt)
+// after the ranks' reduce-scatter (or all-reduce), Mg [n, 2] the common reference exponents of those rows.
+//   positive row:  loss_v = (ln 2 (Mg + log2 L) - zt) / n_pos,  dP += scale / n_pos * O / L + T
+//   outlier row:   loss_v = sel_loss,                            dP += T
+__global__ __launch_bounds__(256) void head_shard_finish_kernel(const float* packed, const float* Mg, const int32_t* pool_label,
+                                                                const float* sel_loss, int D, float scale, float inv_pos,
+                                                                float* row_loss, float* dP) {
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const bool pos = pool_label[i] >= 0;
+  const float* r0 = packed + ((size_t)i * 2) * (2 * D + 2);
+  const float* r1 = r0 + (2 * D + 2);
+  const float L0 = pos ? r0[2 * D] : 1.f, L1 = pos ? r1[2 * D] : 1.f;
+  const float k0 = pos ? scale * inv_pos / L0 : 0.f, k1 = pos ? scale * inv_pos / L1 : 0.f;
+  for (int d = tid; d < D; d += 256) dP[(size_t)i * D + d] = (k0 * r0[d] + r0[D + d]) + (k1 * r1[d] + r1[D + d]);
+  if (tid < 2) {
+    const float* r = tid ? r1 : r0;
+    const float L = tid ? L1 : L0;
+    row_loss[i * 2 + tid] = pos ? (0.6931471805599453f * (Mg[i * 2 + tid] + log2f(L)) - r[2 * D + 1]) * inv_pos
+                                : (sel_loss ? sel_loss[i * 2 + tid] : 0.f);
   }
 }
 
@@ -1414,13 +1501,15 @@ static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const f
                              const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
                              const int32_t* src2, int32_t n_special, int32_t n_pos, float* out_M, float* out_L,
                              float* out_zt, float* out_O, float* out_T, float* cand_val, int32_t* cand_col,
-                             void* workspace, size_t workspace_bytes, void* stream, const float* sv_thr) {
+                             void* workspace, size_t workspace_bytes, void* stream, const float* sv_thr,
+                             float* packed = nullptr, int32_t* fixed_ref_out = nullptr) {
   Plan pl;
   int rc = make_plan(cfg, &pl);
   if (rc != VLSFR_OK) return rc;
-  if (!p || !g || !queue || !pool_label || !out_M || !out_L || !out_zt || !out_O || !out_T || !cand_val || !cand_col ||
-      !workspace)
+  if (!p || !g || !queue || !pool_label || !out_M || !cand_val || !cand_col || !workspace ||
+      (!packed && (!out_L || !out_zt || !out_O || !out_T)))
     return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: null argument");
+  if (fixed_ref_out) *fixed_ref_out = (packed && pl.fast) ? 1 : 0;
   const bool sv = cfg->loss_type == 2;
   if (sv && !sv_thr)
     return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial: SV needs the global thresholds (vlsfr_head_shard_sv_thr + all-reduce(max), then vlsfr_head_shard_partial_sv)");
@@ -1509,6 +1598,8 @@ static int shard_partial_impl(const vlsfr_head_cfg* cfg, const float* p, const f
   sf.cand_val = cand_val;
   sf.cand_col = cand_col;
   sf.sv_thr = sv ? thr : nullptr;
+  sf.packed = packed;
+  sf.fixed_ref = (packed && pl.fast) ? 1 : 0;
   const int nw = pl.n_chunks > n_special ? pl.n_chunks : n_special;
   const size_t lds_f = (size_t)(16 + ((nw + 1) & ~1)) * 4 + (size_t)n_special * 8 + (size_t)4 * D * 4 + (size_t)n_special * 4 + 16;
   if (lds_f > 160 * 1024) return fail(VLSFR_EINVAL, "head_finish_shard: too many special columns for one LDS image");
@@ -1571,11 +1662,56 @@ int vlsfr_head_shard_sv_thr(const vlsfr_head_cfg* cfg, const float* p, const flo
 int vlsfr_head_outlier_accum(const vlsfr_head_cfg* cfg, const float* g, const float* queue, const int32_t* special_col,
                              const int32_t* src1, const int32_t* src2, int32_t n_special, const int32_t* sel_col,
                              const float* sel_w, int32_t k, float* T, void* stream) {
-  if (!cfg || !g || !queue || !sel_col || !sel_w || !T || k < 1 || k > KTOP)
+  return vlsfr_head_outlier_accum_strided(cfg, g, queue, special_col, src1, src2, n_special, sel_col, sel_w, k, T,
+                                          cfg ? cfg->D : 0, stream);
+}
+
+int vlsfr_head_outlier_accum_strided(const vlsfr_head_cfg* cfg, const float* g, const float* queue, const int32_t* special_col,
+                                     const int32_t* src1, const int32_t* src2, int32_t n_special, const int32_t* sel_col,
+                                     const float* sel_w, int32_t k, float* T, int32_t t_stride, void* stream) {
+  if (!cfg || !g || !queue || !sel_col || !sel_w || !T || k < 1 || k > KTOP || t_stride < cfg->D)
     return fail(VLSFR_EINVAL, "vlsfr_head_outlier_accum: bad argument");
   hipLaunchKernelGGL(head_outlier_accum_kernel, dim3(cfg->B, 2), dim3(256), 0, (hipStream_t)stream, g, queue, cfg->Q,
-                     cfg->D, cfg->slot_lo, special_col, src1, src2, n_special, sel_col, sel_w, k, T);
+                     cfg->D, cfg->slot_lo, special_col, src1, src2, n_special, sel_col, sel_w, k, T, t_stride);
   VLSFR_HIP_CHECK_LAUNCH("head_outlier_accum launch");
+  return VLSFR_OK;
+}
+
+int vlsfr_head_shard_partial_packed(const vlsfr_head_cfg* cfg, const float* p, const float* g, const float* queue,
+                                    const int32_t* pool_label, const int32_t* special_col, const int32_t* src1,
+                                    const int32_t* src2, int32_t n_special, int32_t n_pos, const float* sv_thr, float* packed,
+                                    float* out_M, float* cand_val, int32_t* cand_col, int32_t* fixed_ref, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!packed || !fixed_ref) return fail(VLSFR_EINVAL, "vlsfr_head_shard_partial_packed: null argument");
+  return shard_partial_impl(cfg, p, g, queue, pool_label, special_col, src1, src2, n_special, n_pos, out_M, nullptr, nullptr,
+                            nullptr, nullptr, cand_val, cand_col, workspace, workspace_bytes, stream, sv_thr, packed, fixed_ref);
+}
+
+int vlsfr_head_shard_topk_merge(const vlsfr_head_cfg* cfg, const float* cand_val, const int32_t* cand_col, int32_t world,
+                                const int32_t* pool_label, int32_t n_out, int32_t* sel_col, float* sel_w, float* sel_loss,
+                                void* stream) {
+  if (!cfg || !cand_val || !cand_col || !pool_label || !sel_col || !sel_w || !sel_loss || world < 1 || n_out < 1 ||
+      cfg->hard_neg < 1 || cfg->hard_neg > KTOP)
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_topk_merge: bad argument");
+  const float inv = 1.f / ((float)n_out * (float)cfg->hard_neg);
+  hipLaunchKernelGGL(head_topk_merge_kernel, dim3((2 * cfg->B + 255) / 256), dim3(256), 0, (hipStream_t)stream, cand_val,
+                     cand_col, world, cfg->B, cfg->hard_neg, pool_label, inv, sel_col, sel_w, sel_loss);
+  VLSFR_HIP_CHECK_LAUNCH("head_topk_merge launch");
+  return VLSFR_OK;
+}
+
+int vlsfr_head_shard_finish(const vlsfr_head_cfg* cfg, const float* packed, const float* Mg, const int32_t* pool_label,
+                            const float* sel_loss, int32_t n_rows, int32_t n_pos, float* row_loss, float* loss_out, float* dP,
+                            void* stream) {
+  if (!cfg || !packed || !Mg || !pool_label || !row_loss || !loss_out || !dP || n_rows < 1)
+    return fail(VLSFR_EINVAL, "vlsfr_head_shard_finish: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const float inv_pos = 1.f / (float)(n_pos > 0 ? n_pos : 1);
+  hipLaunchKernelGGL(head_shard_finish_kernel, dim3(n_rows), dim3(256), 0, st, packed, Mg, pool_label, sel_loss, cfg->D,
+                     cfg->scale, inv_pos, row_loss, dP);
+  VLSFR_HIP_CHECK_LAUNCH("head_shard_finish launch");
+  hipLaunchKernelGGL(head_loss_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, 2 * n_rows, loss_out);
+  VLSFR_HIP_CHECK_LAUNCH("head_loss_reduce launch");
   return VLSFR_OK;
 }
 

@@ -16,8 +16,11 @@
 
 namespace vlsfr {
 int g_bn_chain = 1;   // "bn_chain": bn1 backward of block k accumulates the reduction of bn3 of block k - 1 (vlsfr_bn_backward_chain)
+int g_dgrad_bnred = 1;   // "dgrad_bnred": the reductions of bn2 / bn1 backward come from the epilogue of the input-gradient
+                         // convolution that writes their dY (vlsfr_conv2d_dgrad_bnred) instead of a kernel of their own
 }
 using vlsfr::g_bn_chain;
+using vlsfr::g_dgrad_bnred;
 
 namespace {
 
@@ -333,10 +336,17 @@ int backward_block(const vlsfr_iresnet* n, int k, int cur_i, bool chained, bool 
   // main branch
   RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st, chained ? 1 : 0));
   RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-  RUN(vlsfr_conv2d_dgrad(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, st));                 // d a2
-  RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st));   // d c1
+  // the input-gradient convolutions accumulate the reductions of the BatchNorm backward that reads their output
+  const int fused = g_dgrad_bnred ? 1 : 0;
+  auto red_of = [&](const Bn& bn, const void* x) {
+    return vlsfr_bn_red{x, (const float*)(ctx + bn.off_mean), (const float*)(ctx + bn.off_invstd), params[bn.p_w], params[bn.p_b],
+                        bn.p_slope >= 0 ? params[bn.p_slope] : nullptr, (float*)(ctx + bn.off_red)};
+  };
+  const vlsfr_bn_red r2 = red_of(b.bn2, ctx + b.c1), r1 = red_of(b.bn1, x_in);
+  RUN(vlsfr_conv2d_dgrad_bnred(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, fused ? &r2 : nullptr, st));   // d a2
+  RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st, fused));   // d c1
   RUN(vlsfr_conv2d_wgrad_ws(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-  RUN(vlsfr_conv2d_dgrad(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, st));                 // d a1 (in t2)
+  RUN(vlsfr_conv2d_dgrad_bnred(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, fused ? &r1 : nullptr, st));   // d a1 (in t2)
   const char* add = dout;
   if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
     RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
@@ -346,7 +356,7 @@ int backward_block(const vlsfr_iresnet* n, int k, int cur_i, bool chained, bool 
   }
   // d x_in = bn1 backward of d a1, plus the shortcut gradient; x_in is the output of block k - 1, so this IS the dY of
   // that block's bn3: its reduction is accumulated here (one read of c2 instead of a kernel reading dout and c2)
-  return bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st, 0,
+  return bn_backward(b.bn1, t2, x_in, t1, Min, b.H * b.W, add, 0, params, grads, ctx, st, fused,
                      chain_prev ? &n->blocks[k - 1].bn3 : nullptr, chain_prev ? ctx + n->blocks[k - 1].c2 : nullptr);
 }
 

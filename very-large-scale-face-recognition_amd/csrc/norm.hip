@@ -371,15 +371,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
             dz = neg ? dyv * sl[j] : dyv;
           }
           v[0][j] += dz;
-          v[1][j] += dz * xf;
+          v[1][j] += dz * (xf - c_mean[j]);   // centred: no cancellation against mean * sum dz when |mean| >> sigma
         }
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {   // sum dz*xhat from the raw-x sum (linear, so it commutes with the reduction)
-    v[1][j] = c_is[j] * (v[1][j] - c_mean[j] * v[0][j]);
-  }
+  for (int j = 0; j < 8; ++j) v[1][j] *= c_is[j];   // sum dz * xhat
   block_reduce_to_replica<3>(v, m, C, sh, a.red);
 }
 
@@ -412,9 +410,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   __syncthreads();
   const RowMap m = row_map(C);
   if (!NEXT && !m.active) return;
-  float nv[3][8];   // NEXT: sum dx, sum dx * nx (raw), unused
+  float nv[3][8];   // NEXT: sum dx, sum dx * (nx - mean of nx), unused
+  float c_is2[8], c_mean2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) nv[0][j] = nv[1][j] = nv[2][j] = 0.f;
+  load8(NEXT ? a.n_invstd : nullptr, m.col * 8, 1.f, c_is2);
+  load8(NEXT ? a.n_mean : nullptr, m.col * 8, 0.f, c_mean2);
   if (m.active) {
   // dx = k0*(dz - k1 - xhat*k2) = A*dz + Bx*x + Cc with xhat = x*invstd - mean*invstd folded in;
   // dz = dy * (z <= 0 ? slope : 1): As = A*slope
@@ -478,18 +479,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
         for (int j = 0; j < 8; ++j) {
           const float dz = ov.get(j);            // the value the following BatchNorm reads back
           nv[0][j] += dz;
-          nv[1][j] += dz * nxv[u].get(j);
+          nv[1][j] += dz * (nxv[u].get(j) - c_mean2[j]);   // centred, as in bn_bwd_reduce_kernel
         }
       }
     }
   }
   }   // m.active
   if (NEXT) {
-    float c_is2[8], c_mean2[8];
-    load8(a.n_invstd, m.col * 8, 1.f, c_is2);
-    load8(a.n_mean, m.col * 8, 0.f, c_mean2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) nv[1][j] = c_is2[j] * (nv[1][j] - c_mean2[j] * nv[0][j]);
+    for (int j = 0; j < 8; ++j) nv[1][j] *= c_is2[j];
     __syncthreads();   // sh (k0, k1, k2) has been consumed by every thread
     block_reduce_to_replica<3>(nv, m, C, sh, a.n_red);
   }
@@ -856,6 +854,23 @@ int vlsfr_bn_backward_chain(const void* dy, const void* x, void* dx, int64_t M, 
   }
 #undef VLSFR_CASE
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward apply");
+  return VLSFR_OK;
+}
+
+int vlsfr_bn_backward_reduce(const void* dy, const void* x, int64_t M, int32_t C, int32_t HW, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
+                             void* stream) {
+  if (!dy || !x || !mean || !invstd || !red || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
+    return fail(VLSFR_EINVAL, "vlsfr_bn_backward_reduce: bad argument");
+  int RB, nblk;
+  bn_geom(M, C, &RB, &nblk);
+  BnBwdArgs a{(const u16*)dy, (const u16*)x, nullptr, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
+              nullptr, nullptr, nullptr, nullptr, 0, g_bn_xcd && nblk >= 16, nullptr, nullptr, nullptr, nullptr};
+  const dim3 grid(nblk), block(256);
+  const size_t shb = 3 * C * sizeof(float);
+  if (slope) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, shb, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, shb, (hipStream_t)stream, a);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward_reduce");
   return VLSFR_OK;
 }
 

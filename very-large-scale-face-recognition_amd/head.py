@@ -324,31 +324,51 @@ class ShardedDcpHead(object):
             self._book.undo(plan, undo)
         return st
 
+    def _bufs(self, slot, B, dev):
+        """Per-pass output buffers, kept across steps (two slots: the rollback and the committing pass of a step may be in
+        flight together); nothing here is allocated per pass."""
+        key = (B, str(dev), self.hard_neg)
+        bufs = self.__dict__.setdefault("_pass_bufs", {})
+        cur = bufs.get(slot)
+        if cur is None or cur["key"] != key:
+            f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+            i32 = lambda *sh: torch.empty(*sh, dtype=torch.int32, device=dev)
+            k = self.hard_neg
+            cur = dict(key=key, packed=f32(B, 2, 2 * self.D + 2), M=f32(B, 2), cand_val=f32(B, 2, 10), cand_col=i32(B, 2, 10),
+                       sel_col=i32(B, 2, k), sel_w=f32(B, 2, k), sel_loss=f32(B, 2), row_loss=f32(B, 2), loss=f32(1),
+                       dP=f32(B, self.D))
+            bufs[slot] = cur
+        return cur
+
     def sweep(self, st):
-        """Local sweep over this rank's slots for all rows (st["thr"] must hold the GLOBAL thresholds for SV)."""
+        """Local sweep over this rank's slots for all rows (st["thr"] must hold the GLOBAL thresholds for SV); the per-row
+        state lands in st["packed"] [B, 2, 2 D + 2] = (O | T | L | zt), the layout the ranks sum (vlsfr_head_shard_partial_packed)."""
         cfg, plan, tab_d, pd, gd = st["cfg"], st["plan"], st["tab_d"], st["pd"], st["gd"]
         B, dev = int(pd.shape[0]), pd.device
-        f32 = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
-        st.update(M=f32(B, 2), L=f32(B, 2), zt=f32(B, 2), O=f32(B, 2, self.D), T=f32(B, 2, self.D),
-                  cand_val=f32(B, 2, 10), cand_col=torch.empty(B, 2, 10, dtype=torch.int32, device=dev))
+        bufs = self._bufs(0 if st["transactional"] else 1, B, dev)
+        st.update(packed=bufs["packed"], M=bufs["M"], cand_val=bufs["cand_val"], cand_col=bufs["cand_col"], bufs=bufs)
         base, n = tab_d.data_ptr(), B
         at = lambda k: ctypes.c_void_p(base + 4 * k * n)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
-        head = (ctypes.byref(cfg), P(pd), P(gd), P(self.queue), at(0), at(1), at(4), at(7),
-                ctypes.c_int32(plan.n_special), ctypes.c_int32(plan.n_pos))
-        tail = (P(st["M"]), P(st["L"]), P(st["zt"]), P(st["O"]), P(st["T"]), P(st["cand_val"]), P(st["cand_col"]),
-                P(self._ws), ctypes.c_size_t(self._ws.numel()), _stream_ptr())
+        thr = None
         if self.loss_type == "SV":
-            fn = self.L.vlsfr_head_shard_partial_sv
-            fn.restype = ctypes.c_int
-            thr = st["thr"].contiguous()
-            st["thr"] = thr
-            _lib.check(fn(*head, P(thr), *tail), "vlsfr_head_shard_partial_sv")
-        else:
-            fn = self.L.vlsfr_head_shard_partial
-            fn.restype = ctypes.c_int
-            _lib.check(fn(*head, *tail), "vlsfr_head_shard_partial")
+            thr = st["thr"] = st["thr"].contiguous()
+        fixed = ctypes.c_int32(0)
+        fn = self.L.vlsfr_head_shard_partial_packed
+        fn.restype = ctypes.c_int
+        _lib.check(fn(ctypes.byref(cfg), P(pd), P(gd), P(self.queue), at(0), at(1), at(4), at(7), ctypes.c_int32(plan.n_special),
+                      ctypes.c_int32(plan.n_pos), P(thr) if thr is not None else None, P(st["packed"]), P(st["M"]),
+                      P(st["cand_val"]), P(st["cand_col"]), ctypes.byref(fixed), P(self._ws), ctypes.c_size_t(self._ws.numel()),
+                      _stream_ptr()), "vlsfr_head_shard_partial_packed")
+        st["fixed_ref"] = bool(fixed.value)
         return st
+
+    # views of the packed state (tests, tools)
+    @staticmethod
+    def unpack(st):
+        D = (st["packed"].shape[2] - 2) // 2
+        pk = st["packed"]
+        return dict(O=pk[:, :, :D], T=pk[:, :, D:2 * D], L=pk[:, :, 2 * D], zt=pk[:, :, 2 * D + 1])
 
     def partial(self, p_all, g_all, probe_label, gallery_label, transactional, comm=None):
         st = self.begin(p_all, g_all, probe_label, gallery_label, transactional)
@@ -359,73 +379,83 @@ class ShardedDcpHead(object):
         return self.sweep(st)
 
     def combine(self, st, comm, own_rows=None):
-        """comm: all_reduce_max(t), all_gather(t) -> [world, ...], and all_reduce_sum(t) or — with own_rows = (r0, r1),
-        the rows of the gathered batch this rank's probe images produced — reduce_scatter_rows(t): the packed
-        softmax state is then summed straight into its owner, and finish() yields the loss share and dL/dp of those
-        rows only (half the bytes of the all-reduce, 1/W of the finish work)."""
-        B, k = st["M"].shape[0], self.hard_neg
-        plan = st["plan"]
+        """The collectives of a pass.  comm: all_reduce_max(t), all_gather(t) -> [world, ...], and all_reduce_sum(t) or — with
+        own_rows = (r0, r1), the rows of the gathered batch this rank's probe images produced — reduce_scatter_rows(t): the
+        packed softmax state is then summed straight into its owner, and finish() yields the loss share and dL/dp of those
+        rows only (half the bytes of the all-reduce, 1/W of the finish work).
+        all-reduce(max): only when the fp32-pool sweep ran (st["fixed_ref"] False) — the shadow sweeps emit the state
+        relative to the row's fixed reference exponent, which every rank computes identically from the probe row.
+        all-gather of the hard-negative candidates: only when the batch has outlier rows."""
+        B, k = int(st["M"].shape[0]), self.hard_neg
+        plan, bufs, packed = st["plan"], st["bufs"], st["packed"]
         n_out = B - plan.n_pos
-        M = comm.all_reduce_max(st["M"].clone())
-        w = torch.exp2(st["M"] - M)                                        # [B, 2] rescale to the global maximum
-        w = torch.where(st["M"] <= -1e29, torch.zeros_like(w), w)
-        sel_loss = torch.zeros(B, 2, device=M.device)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        Mg = st["M"]
+        if not st["fixed_ref"]:
+            Mg = comm.all_reduce_max(st["M"].clone())
+            w = torch.exp2(st["M"] - Mg)                                     # [B, 2] rescale to the global maximum
+            w = torch.where(st["M"] <= -1e29, torch.zeros_like(w), w)
+            D = self.D
+            packed[:, :, :D] *= w.unsqueeze(2)
+            packed[:, :, 2 * D] *= w
+        sel_loss = None
         if n_out > 0:                                                        # hard negatives: global top-k of the candidates
-            cv = comm.all_gather(st["cand_val"])                             # [W, B, 2, 10]
-            cc = comm.all_gather(st["cand_col"])
-            cv = cv.permute(1, 2, 0, 3).reshape(B, 2, -1)
-            cc = cc.permute(1, 2, 0, 3).reshape(B, 2, -1)
-            top, idx = torch.topk(cv, k, dim=2)
-            col = torch.gather(cc, 2, idx)
-            ok = (top > -1e29) & (col >= 0) & (top >= 0)                     # clip(min=0): negatives contribute nothing
-            inv = 1.0 / (n_out * k)
-            sel_w = torch.where(ok, torch.full_like(top, inv), torch.zeros_like(top))
-            is_out = (st["label"] < 0).view(B, 1, 1)
-            sel_w = sel_w * is_out
-            sel_loss = (torch.clamp(top, min=0) * (top > -1e29) * is_out).sum(2) * inv
-            fn = self.L.vlsfr_head_outlier_accum
+            cv = comm.all_gather(st["cand_val"]).contiguous()                # [W, B, 2, 10]
+            cc = comm.all_gather(st["cand_col"]).contiguous()
+            fn = self.L.vlsfr_head_shard_topk_merge
             fn.restype = ctypes.c_int
-            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            _lib.check(fn(ctypes.byref(st["cfg"]), P(cv), P(cc), ctypes.c_int32(int(cv.shape[0])), P(st["label"]),
+                          ctypes.c_int32(n_out), P(bufs["sel_col"]), P(bufs["sel_w"]), P(bufs["sel_loss"]), _stream_ptr()),
+                       "vlsfr_head_shard_topk_merge")
             base, n = st["tab_d"].data_ptr(), B
             at = lambda j: ctypes.c_void_p(base + 4 * j * n)
-            col_c, w_c = col.contiguous().int(), sel_w.contiguous().float()
-            _lib.check(fn(ctypes.byref(st["cfg"]), P(st["gd"]), P(self.queue), at(1), at(4), at(7),
-                          ctypes.c_int32(plan.n_special), P(col_c), P(w_c), ctypes.c_int32(k), P(st["T"]),
-                          _stream_ptr()), "vlsfr_head_outlier_accum")
-            st["_keep"] = (col_c, w_c)
-        packed = torch.cat([st["O"] * w.unsqueeze(2), st["T"], (st["L"] * w).unsqueeze(2), st["zt"].unsqueeze(2)], dim=2)
+            fn = self.L.vlsfr_head_outlier_accum_strided
+            fn.restype = ctypes.c_int
+            _lib.check(fn(ctypes.byref(st["cfg"]), P(st["gd"]), P(self.queue), at(1), at(4), at(7), ctypes.c_int32(plan.n_special),
+                          P(bufs["sel_col"]), P(bufs["sel_w"]), ctypes.c_int32(k),
+                          ctypes.c_void_p(packed.data_ptr() + 4 * self.D), ctypes.c_int32(2 * self.D + 2), _stream_ptr()),
+                       "vlsfr_head_outlier_accum_strided")
+            sel_loss = bufs["sel_loss"]
+            st["_keep"] = (cv, cc)
         if own_rows is None:
-            packed = comm.all_reduce_sum(packed.contiguous())
+            summed = comm.all_reduce_sum(packed)
             own_rows = (0, B)
         else:
-            packed = comm.reduce_scatter_rows(packed.contiguous())
-        st.update(Mg=M, packed=packed, sel_loss=sel_loss, rows=own_rows)
+            summed = comm.reduce_scatter_rows(packed)
+        st.update(Mg=Mg, summed=summed, sel_loss=sel_loss, rows=own_rows)
         return st
 
     def finish(self, st):
         """Loss and dL/dp of the rows combine() left on this rank: all rows of the batch (all-reduce form: the loss is
         then identical on every rank), or this rank's own rows (reduce-scatter form: the losses of the ranks sum to
-        the reference loss)."""
-        D, plan = self.D, st["plan"]
+        the reference loss) — one kernel (vlsfr_head_shard_finish) + the deterministic loss sum."""
+        D, plan, bufs = self.D, st["plan"], st["bufs"]
         r0, r1 = st.get("rows", (0, int(st["M"].shape[0])))
-        O, T = st["packed"][:, :, :D], st["packed"][:, :, D:2 * D]
-        Lg, zt = st["packed"][:, :, 2 * D], st["packed"][:, :, 2 * D + 1]
-        pos = (st["label"][r0:r1] >= 0).view(-1, 1)
-        inv_pos = 1.0 / max(plan.n_pos, 1)
-        safe_L = torch.where(pos, Lg, torch.ones_like(Lg))
-        row_loss = torch.where(pos, (0.6931471805599453 * (st["Mg"][r0:r1] + torch.log2(safe_L)) - zt) * inv_pos,
-                               st["sel_loss"][r0:r1])
-        dP = torch.where(pos.unsqueeze(2), self.scale * inv_pos * O / safe_L.unsqueeze(2) + T, T).sum(1)
+        n = r1 - r0
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        summed = st["summed"]
+        if summed.shape[0] != n:                                             # all-reduce form: every row is here
+            summed = summed[r0:r1]
+        Mg = st["Mg"][r0:r1]
+        sel = st["sel_loss"][r0:r1] if st["sel_loss"] is not None else None
+        dP, loss = bufs["dP"][:n], bufs["loss"]
+        fn = self.L.vlsfr_head_shard_finish
+        fn.restype = ctypes.c_int
+        _lib.check(fn(ctypes.byref(st["cfg"]), P(summed), P(Mg), ctypes.c_void_p(st["label"].data_ptr() + 4 * r0),
+                      P(sel) if sel is not None else None, ctypes.c_int32(n), ctypes.c_int32(plan.n_pos), P(bufs["row_loss"]),
+                      P(loss), P(dP), _stream_ptr()), "vlsfr_head_shard_finish")
         if not st["transactional"]:
             sc = self.L.vlsfr_pool_scatter
             sc.restype = ctypes.c_int
-            base, n = st["tab_d"].data_ptr(), int(st["M"].shape[0])
-            at = lambda j: ctypes.c_void_p(base + 4 * j * n)
+            base, nb = st["tab_d"].data_ptr(), int(st["M"].shape[0])
+            at = lambda j: ctypes.c_void_p(base + 4 * j * nb)
             _lib.check(sc(ctypes.c_void_p(self.queue.data_ptr()), ctypes.c_int64(self.Qs), ctypes.c_int32(D),
-                          ctypes.c_void_p(st["gd"].data_ptr()), at(10), at(11), ctypes.c_int32(n),
+                          ctypes.c_void_p(st["gd"].data_ptr()), at(10), at(11), ctypes.c_int32(nb),
                           ctypes.c_int32(self.slot_lo),
                           ctypes.c_void_p(self.shadow.scatter_target()), _stream_ptr()),
                        "vlsfr_pool_scatter")
-            self.shadow.after_scatter(at(11), n, self.slot_lo)
+            self.shadow.after_scatter(at(11), nb, self.slot_lo)
         self._keep = st
-        return row_loss.sum(), dP
+        # the autograd node (_HeadFn) clones the loss itself and SAVES dP: dP gets its own storage here, the pass buffers are
+        # rewritten by the next pass of this kind
+        return loss.reshape(()), dP.clone()

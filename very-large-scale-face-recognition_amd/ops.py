@@ -203,3 +203,25 @@ def conv2d_wgrad_ws(dy, x, desc, dw=None, splitk=0):
     _call("vlsfr_conv2d_wgrad_ws", ctypes.byref(desc), _p(dy), _p(x), _p(dw), ctypes.c_int32(splitk), _p(ws),
           ctypes.c_size_t(n), _st())
     return dw, n
+
+
+class BnRed(ctypes.Structure):      # vlsfr_bn_red
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "mean", "invstd", "gamma", "beta", "slope", "red")]
+
+
+def conv2d_dgrad_bnred(dy, wT, desc, x, mean, invstd, gamma=None, beta=None, slope=None):
+    """Input gradient with the reduction of the BatchNorm (+ PReLU) backward that consumes it accumulated by the epilogue
+    (vlsfr_conv2d_dgrad_bnred).  Returns (dx, red [BN_REPL, 3, Cin])."""
+    dx = torch.empty(desc.N, desc.H, desc.W, desc.Cin, dtype=torch.bfloat16, device=dy.device)
+    red = torch.zeros(BN_REPL, 3, desc.Cin, dtype=torch.float32, device=dy.device)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    r = BnRed(ptr(x), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(slope), ptr(red))
+    _call("vlsfr_conv2d_dgrad_bnred", ctypes.byref(desc), _p(dy), _p(wT), _p(dx), ctypes.byref(r), _st())
+    return dx, red
+
+
+def bn_backward_reduce(dy, x, M, C, HW, mean, invstd, gamma=None, beta=None, slope=None):
+    red = torch.zeros(BN_REPL, 3, C, dtype=torch.float32, device=x.device)
+    _call("vlsfr_bn_backward_reduce", _p(dy), _p(x), ctypes.c_int64(M), ctypes.c_int32(C), ctypes.c_int32(HW), _p(mean),
+          _p(invstd), _p(gamma), _p(beta), _p(slope), _p(red), _st())
+    return red

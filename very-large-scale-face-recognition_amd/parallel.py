@@ -136,6 +136,82 @@ class Comm(object):
         return self.reduce_scatter_sum(out, t.contiguous())
 
 
+class RehearsalDist(object):
+    """Stand-in for the torch.distributed module that lets ONE process run rank 0's step of a `world`-rank job
+    (bench.py --rehearse-world, tests): shard-local pool, gathered batch of world * B rows, replicated LRU replaying the
+    global label sequence, partitioned optimizer — with every collective replaced by a local operation of the same
+    shape (RehearsalComm), so what is measured is rank 0's compute at the node's shapes WITHOUT wire time.  The other
+    ranks' labels are drawn here (main.py:53-60 structure: an id half shared between the two views, an instance half)."""
+
+    class ReduceOp(object):
+        MAX, SUM = "max", "sum"
+
+    def __init__(self, world, n_id, seed=0):
+        self.world, self.n_id = int(world), int(n_id)
+        self.rng = np.random.default_rng(seed)
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_rank(self, group=None):
+        return 0
+
+    def get_backend(self, group=None):
+        return "rehearsal"
+
+    def new_group(self, backend=None):
+        return None
+
+    def barrier(self, group=None):
+        pass
+
+    def broadcast(self, t, src=0, group=None):
+        return t
+
+    def all_reduce(self, t, op=None, group=None):
+        return t
+
+    def all_gather(self, out, t, group=None):
+        """Only the host label exchange comes here (DataParallelFFC.exchange_labels: t = [2, B] int64)."""
+        out[0].copy_(t)
+        B = t.shape[-1]
+        h = B // 2
+        for r in range(1, self.world):
+            ids = self.rng.choice(self.n_id, size=h, replace=False)
+            for v in range(2):
+                out[r][v] = torch.from_numpy(np.concatenate([ids, self.rng.integers(0, self.n_id, size=B - h)]).astype(np.int64))
+
+
+class RehearsalComm(object):
+    """Comm with the wire removed (see RehearsalDist): gathers tile this rank's tensor (rows rolled, so the other ranks'
+    embedding rows are different unit vectors), reductions keep this rank's contribution, scatters keep its slice."""
+
+    def __init__(self, world):
+        self.world, self.rank, self.rccl, self.solo = int(world), 0, False, False
+
+    def broadcast(self, t, src=0):
+        return t
+
+    def all_reduce(self, t, op="sum"):
+        return t
+
+    all_reduce_max = all_reduce_sum = lambda self, t: t
+
+    def all_gather(self, t):
+        return torch.stack([t.roll(r, 0) if t.dim() > 0 and t.shape[0] > 1 else t for r in range(self.world)])
+
+    def all_gather_into(self, out, shard):
+        out[:shard.numel()].copy_(shard.reshape(-1))          # the other ranks' slices keep their (valid, older) contents
+        return out
+
+    def reduce_scatter_sum(self, out, inp):
+        out.copy_(inp[:out.shape[0]])
+        return out
+
+    def reduce_scatter_rows(self, t):
+        return t[:t.shape[0] // self.world].contiguous()
+
+
 class DataParallelFFC(object):
     """Data-parallel backbones over a replicated pool; also the base of ShardedFFC (everything but the head)."""
     overlap_head = os.environ.get("VLSFR_OVERLAP_HEAD", "0") == "1"
@@ -143,7 +219,7 @@ class DataParallelFFC(object):
     def __init__(self, model, dist):
         self.m = model
         self.dist = dist
-        self.comm = Comm(dist)
+        self.comm = RehearsalComm(dist.world) if isinstance(dist, RehearsalDist) else Comm(dist)
         self.world, self.rank = self.comm.world, self.comm.rank
         self.rccl = self.comm.rccl
         self.cpu_group = dist.new_group(backend="gloo")        # labels (host arrays) travel here, see module docstring
