@@ -318,7 +318,10 @@ int vlsfr_dwconv_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
 /* Per-channel reductions are kept in VLSFR_BN_REPL replicated accumulators (fp32
  * [VLSFR_BN_REPL][n][C], pre-zeroed by the caller, accumulated atomically) and folded by the
  * finalize step. */
+#ifndef VLSFR_BN_REPL
 #define VLSFR_BN_REPL 32
+#endif
+int vlsfr_bn_repl(void);   /* the value this library was compiled with */
 /* sums [REPL][2][C]: sum and sum of squares over the M rows of x */
 int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream);
 /* y = prelu(bn(x)) + residual from the statistics `sums` of x (every block folds the replicas into

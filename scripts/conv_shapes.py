@@ -13,6 +13,9 @@ SHAPES = [(64, 64, 3, 1, 112, 1), (64, 64, 3, 2, 112, 1), (64, 64, 1, 2, 112, 1)
           (128, 128, 3, 2, 56, 1), (64, 128, 1, 2, 56, 1), (128, 128, 3, 1, 28, 24), (128, 256, 3, 1, 28, 1), (256, 256, 3, 2, 28, 1),
           (128, 256, 1, 2, 28, 1), (256, 256, 3, 1, 14, 58), (256, 512, 3, 1, 14, 1), (512, 512, 3, 2, 14, 1), (256, 512, 1, 2, 14, 1),
           (512, 512, 3, 1, 7, 4)]
+if os.environ.get("ONLY"):
+    keep = set(os.environ["ONLY"].split())
+    SHAPES = [sh for sh in SHAPES if "%d_%d_%d_%d_%d" % sh[:5] in keep]
 def timeit(fn, n=10):
     for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()

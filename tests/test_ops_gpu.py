@@ -470,13 +470,16 @@ BNRED_CASES = [(256, 256, 1, 14, 8, True), (256, 256, 1, 14, 8, False), (64, 64,
 
 
 @pytest.mark.parametrize("cin,cout,stride,hw,N,prelu", BNRED_CASES)
-def test_dgrad_epilogue_accumulates_the_batchnorm_backward_reduction(cin, cout, stride, hw, N, prelu, conv_variant):
+def test_dgrad_epilogue_accumulates_the_batchnorm_backward_reduction(cin, cout, stride, hw, N, prelu, conv_variant, request):
     """vlsfr_conv2d_dgrad_bnred: the input gradient is the plain dgrad's bit for bit, and the reduction its epilogue
     accumulated (sum dz, sum dz * xhat, sum dy * min(z, 0) over the ROUNDED gradient) equals the stand-alone reduction kernel
     run on that gradient (same arithmetic, other summation order: 1e-4 of the per-channel scale) and a float64 evaluation.
     Every conv variant: the ones without the fused epilogue take the stand-alone kernel inside the call."""
-    from vlsfr_amd import ops
+    import ctypes
+    from vlsfr_amd import ops, _lib
     torch.manual_seed(cin + cout + hw)
+    request.addfinalizer(lambda: _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(0)))
+    _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(1))       # the fused epilogue wherever it exists, not only where it pays
     d = ops.ConvDesc(N, hw, hw, cin, cout, 3, 3, stride, 1)
     Ho = ops.out_hw(hw, 3, stride, 1)
     w = torch.randn(cout, 3, 3, cin, device="cuda") / np.sqrt(9 * cin)
@@ -511,8 +514,10 @@ def test_dgrad_epilogue_accumulates_the_batchnorm_backward_reduction(cin, cout, 
 def test_dgrad_bnred_1x1_stride2_shortcut():
     """The 1 x 1 stride-2 shortcut's input gradient is zero at the odd positions (one parity-class launch over a memset
     tensor): the fused reduction of that launch is the whole reduction."""
-    from vlsfr_amd import ops
+    import ctypes
+    from vlsfr_amd import ops, _lib
     torch.manual_seed(3)
+    _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(1))
     N, hw, cin, cout = 4, 28, 128, 256
     d = ops.ConvDesc(N, hw, hw, cin, cout, 1, 1, 2, 0)
     w = torch.randn(cout, 1, 1, cin, device="cuda") / np.sqrt(cin)
@@ -525,6 +530,7 @@ def test_dgrad_bnred_1x1_stride2_shortcut():
     dx, red = ops.conv2d_dgrad_bnred(dy, wT, d, x, mean, invstd)
     assert torch.equal(dx, ops.conv2d_dgrad(dy, wT, d))
     ref = ops.bn_backward_reduce(dx, x, M, cin, hw * hw, mean, invstd)
+    _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(0))
     got, want = red.double().sum(0).cpu().numpy(), ref.double().sum(0).cpu().numpy()
     scale = np.abs(want).max(axis=1, keepdims=True) + 1e-12
     np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)

@@ -11,7 +11,8 @@ char* error_buffer() {
 
 extern "C" {
 const char* vlsfr_last_error(void) { return vlsfr::error_buffer(); }
-int vlsfr_version(void) { return 200; }
+int vlsfr_version(void) { return 300; }
+int vlsfr_bn_repl(void) { return VLSFR_BN_REPL; }
 
 // ---- section 10 of include/vlsfr.h: HIP events for cross-stream ordering of the multi-GPU step
 int vlsfr_event_create(void** ev) {

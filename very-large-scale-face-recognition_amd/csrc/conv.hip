@@ -55,6 +55,7 @@ extern int g_dw_wgrad_blocks;   // csrc/dw.hip
 extern int g_dw_strip;          // csrc/dw.hip
 extern int g_bn_chain;          // csrc/iresnet.cpp
 extern int g_dgrad_bnred;       // csrc/iresnet.cpp
+extern int g_bn_repl;           // csrc/norm.hip
 int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
 
@@ -77,6 +78,8 @@ int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range o
 int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
+int g_tile256 = 2;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
+int g_bnred_all = 0;         // "bnred_all": 1 = the fused BatchNorm-backward reduction on every eligible launch (default: where it pays)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
 
@@ -113,6 +116,8 @@ struct ConvArgs {
   const float* red_beta = nullptr;
   const float* red_slope = nullptr;   // PReLU slopes or nullptr (plain BatchNorm)
   float* red_out = nullptr;       // [VLSFR_BN_REPL][3][Mrows], pre-zeroed
+  int repl = 1;                   // replicas of the per-channel accumulators in use (vlsfr::g_bn_repl)
+  int dbg = 0;                    // diagnostics ("conv_dbg"): 4 skip the x-tile DMA, 8 skip the reduction arithmetic, 16 skip its atomics
 };
 
 // Workgroups are dealt to the 8 XCDs round-robin in dispatch order (id % 8), and each XCD has its own L2.  This maps
@@ -137,7 +142,7 @@ __device__ __forceinline__ int swz(int row) {
 
 template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
-                                              int r16, int h, int tid, float* red_lds);
+                                              int r16, int h, int tid, float* red_lds, const char* x_lds = nullptr);
 
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -315,7 +320,7 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
 // atomics) or bf16 output with the fused BatchNorm statistics; red_lds = BM*WN*2 floats of LDS nobody reads.
 template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
-                                              int r16, int h, int tid, float* red_lds) {
+                                              int r16, int h, int tid, float* red_lds, const char* x_lds) {
   // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
   const int mw = m0 + wm * (BM / WM) + 4 * h;     // + 16 i
   const int pw = p0 + wn * (BN / WN) + r16;       // + 16 j
@@ -395,9 +400,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             o[e] = (__bf16)acc[i][j][e];
-            const float f = ok ? (float)o[e] : 0.f;
-            cs[i][e] += f;
-            cq[i][e] += f * f;
+            if constexpr (!RED) {   // forward statistics (an input-gradient launch with the fused reduction has none)
+              const float f = ok ? (float)o[e] : 0.f;
+              cs[i][e] += f;
+              cq[i][e] += f * f;
+            }
           }
           const uint2 u = __builtin_bit_cast(uint2, o);
           w[t][0] = u.x;
@@ -413,23 +420,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     }
   };
   const bool full_tile = p0 + BN <= P && m0 + BM <= a.Mrows;
-  // BatchNorm-backward reduction fused into an input-gradient launch (RED; ConvArgs::red_x): the x tile is fetched with the
-  // store's own addresses (16 bytes per lane), one 16-channel row block (i) ahead of the arithmetic; the first block is
-  // requested BEFORE the stores are issued, so its latency runs under them
-  constexpr int NXQ = RED ? NT / 2 : 1;
-  uint4 xa[NXQ], xb[NXQ];
-  auto loadx = [&](int i, uint4 (&dst)[NXQ]) {
-    if constexpr (RED) {
-      const u16* xbase = a.red_x + (mw - 4 * (h & 1));
-#pragma unroll
-      for (int jp = 0; jp < NT / 2; ++jp) {
-        const int j = 2 * jp + (odd ? 1 : 0);
-        const bool ok = full_tile || (pw + j * 16 < P && mw - 4 * (h & 1) + i * 16 < a.Mrows);
-        dst[jp] = ok ? *(const uint4*)(xbase + (size_t)orow[jp] * a.Mrows + i * 16) : make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  loadx(0, xa);
   if (full_tile) store(std::true_type{});
   else store(std::false_type{});
   // Per-channel sums -> one of VLSFR_BN_REPL replicated accumulators out[rep][q][Mrows].  A lane's partial for channel
@@ -454,7 +444,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
       }
     }
     __syncthreads();
-    float* dst = out + (size_t)(blockIdx.x % VLSFR_BN_REPL) * NQ * a.Mrows;
+    float* dst = out + (size_t)(blockIdx.x % a.repl) * NQ * a.Mrows;
     for (int i = tid; i < NQ * BM; i += NW * 64) {
       const int k = i / BM, ml = i - k * BM;
       float t = 0.f;
@@ -477,17 +467,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     flush(std::integral_constant<int, 2>{}, keep, a.stats);
   }
   if constexpr (RED) {
+    // BatchNorm-backward reduction fused into an input-gradient launch (ConvArgs::red_x).  The x tile [BN pixels][BM
+    // channels] of this output tile was brought into the LDS stage the last k-tile did not use, by LDS-DMA issued under that
+    // k-tile's MFMAs (conv_igemm_glds_kernel: issue_x) — no exposed memory latency, no staging registers; its 16-byte chunks
+    // are XOR-swizzled with the pixel row, so the 8-byte reads below (lane = 4 channels of one pixel, the accumulator
+    // layout) are bank-conflict free.
     // dz = dy * prelu'(z), z = bn(x) = x * zs + zo; sums of dz, dz * (x - mean) (times invstd = dz * xhat) and, for the
     // PReLU slope gradient, dy * z over z <= 0 — from the ROUNDED dy (what the BatchNorm backward reads back)
+    constexpr int XCPR = BM / 8;          // 16-byte chunks per x row
+    const uint32_t x_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)x_lds;
     const bool prelu = a.red_slope != nullptr;
     float keep[3][NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = keep[2][r] = 0.f;
+    if (!(a.dbg & 8))
     static_for<MT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      uint4(&cur)[NXQ] = (i & 1) ? xb : xa;
-      uint4(&nxt)[NXQ] = (i & 1) ? xa : xb;
-      if constexpr (i + 1 < MT) loadx(i + 1, nxt);
       const int mc = mw + i * 16;
       const bool mok = mc < a.Mrows;
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
@@ -505,31 +500,34 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         }
       }
       float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+      const int lchunk = (wm * (BM / WM) + i * 16 + 4 * h) >> 3;     // logical 16-byte chunk of this lane's 4 channels
+      uint2 xr[NT];
 #pragma unroll
-      for (int jp = 0; jp < NT / 2; ++jp) {
-        // undo the store's lane exchange: after the swaps dword k of pixel tile 2 jp + t is xt[t][k] on every lane
-        const auto t0 = __builtin_amdgcn_permlane16_swap(cur[jp].x, cur[jp].z, false, false);
-        const auto t1 = __builtin_amdgcn_permlane16_swap(cur[jp].y, cur[jp].w, false, false);
-        const uint32_t xt[2][2] = {{t0[0], t1[0]}, {t0[1], t1[1]}};
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * (BN / WN) + j * 16 + r16;
+        const uint32_t addr = x_base + (uint32_t)(row * (BM * 2) + ((lchunk ^ (row & (XCPR - 1))) << 4) + ((h & 1) << 3));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(xr[j]) : "v"(addr));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);   // nothing that consumes xr may move above the wait
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int j = 2 * jp + t;
-          const bool ok = full_tile || (pw + j * 16 < P && mok);
+      for (int j = 0; j < NT; ++j) {
+        const uint2 xw = xr[j];
+        const bool ok = full_tile || (pw + j * 16 < P && mok);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t wd = xt[t][e >> 1];
-            const float xf = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
-            const float dyv = ok ? (float)(__bf16)acc[i][j][e] : 0.f;
-            float dz = dyv;
-            if (prelu) {
-              const float z = xf * zs[e] + zo[e];
-              const bool neg = z <= 0.f;
-              s2[e] += neg ? dyv * z : 0.f;
-              dz = neg ? dyv * sl[e] : dyv;
-            }
-            s0[e] += dz;
-            s1[e] += dz * (xf - c_mean[e]);
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t wd = (e >> 1) ? xw.y : xw.x;
+          const float xf = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+          const float dyv = ok ? (float)(__bf16)acc[i][j][e] : 0.f;
+          float dz = dyv;
+          if (prelu) {
+            const float z = xf * zs[e] + zo[e];
+            const bool neg = z <= 0.f;
+            s2[e] += neg ? dyv * z : 0.f;
+            dz = neg ? dyv * sl[e] : dyv;
           }
+          s0[e] += dz;
+          s1[e] += dz * (xf - c_mean[e]);
         }
       }
 #pragma unroll
@@ -539,7 +537,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         fold(s2[e], i, e, keep[2]);
       }
     });
-    flush(std::integral_constant<int, 3>{}, keep, a.red_out);
+    __syncthreads();   // every wave has read its part of the x tile: the sums' scratch below lives in the same LDS stage
+    if (!(a.dbg & 16)) flush(std::integral_constant<int, 3>{}, keep, a.red_out);
   }
 }
 
@@ -685,6 +684,42 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
     if (++is_j >= ntap) {
       is_j = 0;
       is_c0 += BK;
+    }
+  };
+
+  // RED: the [BN pixels][BM channels] tile of the BatchNorm input x that matches this output tile -> LDS stage nk % NST
+  // (free during the last k-tile), 16-byte chunks XOR-swizzled with the pixel row on the SOURCE side like the operands.
+  // Rows are the output rows of the tile: consecutive pixels, or (parity-class launch) the stride-2 positions.
+  auto issue_x = [&]() {
+    if constexpr (RED) {
+      static_assert(NST == 2 && !PP && !SWP && BM * BN * 2 <= (BM + BN) * BK * 2, "RED: the x tile takes the spare stage of the 2-stage ring");
+      constexpr int XRB = BM * 2;                 // x row bytes in LDS
+      constexpr int XCPR = XRB / 16;              // chunks per row
+      constexpr int XRPI = 1024 / XRB;            // rows per DMA instruction
+      constexpr int XI = BN / XRPI / NW;          // instructions per wave
+      const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)a.red_x, 0, (int)((size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows * 2), 0x00020000);
+      char* st = smem + (nk % NST) * STAGE;
+      const int rin = lane / XCPR, pc = lane % XCPR;
+#pragma unroll
+      for (int i = 0; i < XI; ++i) {
+        const int r = (wave * XI + i) * XRPI + rin;             // pixel row of the tile
+        const int lc = pc ^ (r & (XCPR - 1));
+        const int q = p0 + r;
+        int64_t orow = q;
+        if (a.cls) {
+          const int ph = (a.cls - 1) >> 1, pwc = (a.cls - 1) & 1;
+          const int HWc = a.Ho * a.Wo;
+          const int qc = q < P ? q : 0;
+          const int n = qc / HWc;
+          const int rem = qc - n * HWc;
+          const int hh = rem / a.Wo;
+          orow = ((int64_t)n * a.Hf + 2 * hh + ph) * a.Wf + 2 * (rem - hh * a.Wo) + pwc;
+        }
+        const bool ok = q < P && m0 + lc * 8 < a.Mrows;
+        const int off = ok ? (int)((orow * a.Mrows + m0 + lc * 8) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rx, (lds_void_t*)(st + (wave * XI + i) * 1024), 16, off, 0, 0, 0);
+      }
     }
   };
 
@@ -843,8 +878,11 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
     else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + NST - 1 < nk) issue((it + NST - 1) % NST);
+    if (!(a.dbg & 128)) __builtin_amdgcn_s_barrier();                        // dbg 128 (with 32): no barrier (diagnostic)
+    if (it + NST - 1 < nk && !(a.dbg & 32)) issue((it + NST - 1) % NST);   // dbg 32: no DMA after the prologue (diagnostic)
+    if constexpr (RED) {
+      if (it == nk - 1 && !(a.dbg & 4)) issue_x();       // the stage of tile nk - 2 is free: the x tile of the epilogue's reduction goes there
+    }
     const uint32_t sbase = lds0 + (uint32_t)((it % NST) * STAGE);
     // all fragment reads of the tile are issued up front; the MFMAs of k-step kk start as soon as
     // its (MT + NT) reads have returned (counted lgkmcnt), the later reads land underneath them
@@ -870,8 +908,14 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (RED) __builtin_amdgcn_s_barrier();   // every wave's slice of the x tile has landed
+  if (a.dbg & 64) {                                  // diagnostic: no epilogue (one dword per lane keeps the loop alive)
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0];
+    return;
+  }
 
-  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, RED>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)(smem + (nk % NST) * STAGE));
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, RED>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)(smem + (nk % NST) * STAGE),
+                                                 smem + (nk % NST) * STAGE);
 #endif
 }
 
@@ -1555,6 +1599,8 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
 int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   const int P = a.Nimg * a.Ho * a.Wo;
   a.trace = g_conv_trace;
+  a.dbg = g_conv_dbg;
+  a.repl = vlsfr::g_bn_repl;
   if (red_done) *red_done = false;
   // ALGORITHMIC FLOPs of the convolution this launch implements (what bench.py's roofline may count):
   // the input gradient of a stride-2 layer visits every INPUT position, but 3/4 of its taps are the
@@ -1616,7 +1662,22 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
-    else if (a.red_x && !a.out_f32 && a.splitk == 1) {
+    else if (g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * 160 && P <= 256 * 256 && !(a.red_x && g_tile256 == 2) &&
+             !g_bnred_all) {
+      // 256-channel layers with 160 - 256 pixel tiles of 256 (ir100 at batch 256: the 58 + 58 convolutions at 14 x 14, 55 % of the
+      // FLOPs): one 256 x 256 tile per CU, 8 waves.  The LDS-DMA path delivers ~31 B / clk / CU from L2 and bounds the
+      // 128 x 128 tile (64 FLOP per byte) at half the MFMA rate; the 256 x 256 tile needs half the bytes per FLOP, and its
+      // 196 tiles run in ONE round instead of 784 tiles in 1.53 rounds on 512 slots (scripts/conv_shapes.py: 73.4 vs 81.7 us).
+      // "tile256": 0 off, 1 forward + input gradient (the fused BatchNorm-backward reduction has no 256 x 256 form: that
+      // launch then takes the stand-alone reduction kernel), 2 forward only
+      rc = launch_igemm_glds<256, 256, 64, 2, 8>(a, P, st);
+    }
+    else if (a.red_x && !a.out_f32 && a.splitk == 1 && (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) &&
+             (g_bnred_all || (big && !a.cls))) {
+      // measured per launch at batch 256 (scripts/dgrad_bnred_micro.py): the fused epilogue beats "plain launch + stand-alone
+      // reduction kernel" on the 128 x 128 tiles of the stride-1 layers (128 / 256 / 512 channels: 7 - 10 us saved of 20 - 30)
+      // and loses on the 64-channel layers (6 - 12 tile rounds per launch: the epilogue is paid per tile) and on the four
+      // parity-class launches of a stride-2 layer; "bnred_all" = 1 forces it everywhere (tests)
       rc = big ? launch_igemm_glds<128, 128, 64, 2, 4, false, false, true>(a, P, st)
                : launch_igemm_glds<64, 128, 64, 2, 4, false, false, true>(a, P, st);
       if (red_done) *red_done = true;
@@ -1668,6 +1729,19 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "conv_halo")) {
     g_use_halo = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "bn_repl")) {
+    if (value < 1 || value > VLSFR_BN_REPL) return fail(VLSFR_EINVAL, "vlsfr_set_option: bn_repl must be in [1, %d]", VLSFR_BN_REPL);
+    vlsfr::g_bn_repl = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "tile256")) {
+    g_tile256 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "bnred_all")) {
+    g_bnred_all = value != 0;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "conv_dbg")) {
@@ -1871,7 +1945,7 @@ int vlsfr_conv2d_dgrad_bnred(const vlsfr_conv_desc* d, const void* dy, const voi
       if (rc || !bn || done) return rc;
       return bn_red_fallback(d, dx, bn, stream);
     }
-    bool all_done = true;
+    bool all_done = true, any_done = false;
     for (int ph = 0; ph < 2; ++ph)
       for (int pw = 0; pw < 2; ++pw) {
         // virtual tap r' (row offset r' - 1 on the dY grid) <-> filter tap r:  ph = 0: r' = 1 <-> r = 1;
@@ -1892,10 +1966,11 @@ int vlsfr_conv2d_dgrad_bnred(const vlsfr_conv_desc* d, const void* dy, const voi
         rc = run_igemm(a, st, &done);
         if (rc) return rc;
         all_done = all_done && done;
+        any_done = any_done || done;
       }
     if (bn && !all_done) {
-      if (g_use_glds == VLSFR_DEFAULT_CONV_VARIANT) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad_bnred: parity-class launches disagree");
-      return bn_red_fallback(d, dx, bn, stream);   // A/B tile variants carry no RED epilogue: none of the four accumulated
+      if (any_done) return fail(VLSFR_EINVAL, "vlsfr_conv2d_dgrad_bnred: parity-class launches disagree");
+      return bn_red_fallback(d, dx, bn, stream);   // none of the four accumulated (the default for class launches)
     }
     return VLSFR_OK;
   }

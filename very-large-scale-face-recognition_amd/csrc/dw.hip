@@ -17,6 +17,11 @@ int g_dw_wgrad_blocks = 256;   // "dw_wgrad_blocks": workgroups of the one-pass 
 namespace {
 
 constexpr int REPL = VLSFR_BN_REPL;
+}  // namespace
+namespace vlsfr {
+extern int g_bn_repl;   // csrc/norm.hip
+}
+namespace {
 
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
@@ -32,6 +37,7 @@ struct DwArgs {
   int N, H, W, C, Ho, Wo, k, stride, pad;
   int dgrad;         // 0 forward, 1 input gradient
   float* stats;      // forward only: [REPL][2][C] or nullptr
+  int repl = 1;      // replicas in use (vlsfr::g_bn_repl)
 };
 
 // grid-stride over (output position, channel group); cg = C / 8 divides 256 or the tail threads idle
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+    float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
     for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
   }
 }
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void dw_global_fwd_kernel(DwArgs a) {
     a.out[(size_t)n * a.C + c] = __builtin_bit_cast(u16, yb);
     if (a.stats) {
       const float f = (float)yb;
-      float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+      float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
       atomicAdd(&dst[c], f);
       atomicAdd(&dst[a.C + c], f * f);
     }
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void dw3_kernel(DwArgs a) {
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+    float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
     for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
   }
 }
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(256) void dw3_strip_kernel(DwArgs a) {
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % REPL) * 2 * a.C;
+    float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
     for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
   }
 }
@@ -665,6 +671,7 @@ int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, vo
   if (!x || !w || !y) return fail(VLSFR_EINVAL, "vlsfr_dwconv_fwd: null buffer");
   DwArgs a{(const u16*)x, w, (u16*)y, d->N, d->H, d->W, d->Cin, odim(d->H, d->R, d->stride, d->pad),
            odim(d->W, d->S, d->stride, d->pad), d->R, d->stride, d->pad, 0, stats};
+  a.repl = vlsfr::g_bn_repl;
   const int64_t P = (int64_t)a.N * a.Ho * a.Wo;
   const dim3 grid(dw_blocks(P, a.C)), block(256);
   const size_t shb = stats ? 2 * a.C * sizeof(float) : 0;

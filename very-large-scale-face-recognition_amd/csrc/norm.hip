@@ -9,6 +9,14 @@
 
 using namespace vlsfr;
 
+namespace vlsfr {
+// "bn_repl": replicated accumulators in use for the per-channel sums (statistics, backward reductions), <= VLSFR_BN_REPL
+// (what the buffers are sized and zeroed for).  Every consumer block folds the replicas itself, so fewer replicas = less
+// L2 traffic in front of every streaming loop (32 replicas: 64 KB of sums per block against 32 KB of payload at 256
+// channels); more = less same-address contention of the producers' atomics.  8: 108.0 vs 112.5 ms per serial step.
+int g_bn_repl = 8;
+}
+
 namespace {
 
 __device__ __forceinline__ float bf2f(u16 v) { return __uint_as_float((uint32_t)v << 16); }
@@ -40,7 +48,7 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 // same-address atomic contention of thousands of blocks off one cache line; a finalize kernel sums
 // the replicas).
 // ---------------------------------------------------------------------------------------------
-constexpr int REPL = VLSFR_BN_REPL;
+constexpr int REPL = VLSFR_BN_REPL;   // replicas the accumulator buffers are SIZED for; vlsfr::g_bn_repl of them are used
 constexpr int UF = 4;   // independent rows (16-byte loads per tensor) in flight per thread in the streaming loops
 
 struct RowMap {
@@ -72,7 +80,7 @@ __device__ __forceinline__ void load8(const float* arr, int c0, float fill, floa
 // sums over the block of per-thread partials v[NV][8] into out[rep][NV][C]
 template <int NV>
 __device__ __forceinline__ void block_reduce_to_replica(float (&v)[NV][8], const RowMap& m, int C, float* sh,
-                                                        float* out) {
+                                                        float* out, int repl) {
   const int tid = threadIdx.x;
   for (int i = tid; i < NV * C; i += 256) sh[i] = 0.f;
   __syncthreads();
@@ -104,7 +112,7 @@ __device__ __forceinline__ void block_reduce_to_replica(float (&v)[NV][8], const
       for (int j = 0; j < 8; ++j) atomicAdd(&sh[n * C + m.col * 8 + j], v[n][j]);
   }
   __syncthreads();
-  float* dst = out + (size_t)(blockIdx.x % REPL) * NV * C;
+  float* dst = out + (size_t)(blockIdx.x % repl) * NV * C;
   for (int i = tid; i < NV * C; i += 256) atomicAdd(&dst[i], sh[i]);
 }
 
@@ -115,7 +123,7 @@ __device__ __forceinline__ int rows_per_block(int C, int rpb) {
 }
 
 // ---- statistics of x[M, C]: sums[REPL][2][C] (sum, sum of squares), pre-zeroed
-__global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, int C, int RB, float* sums) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, int C, int RB, float* sums, int repl) {
   extern __shared__ float sh[];
   const RowMap m = row_map(C);
   float v[2][8];
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, 
       }
     }
   }
-  block_reduce_to_replica<2>(v, m, C, sh, sums);
+  block_reduce_to_replica<2>(v, m, C, sh, sums, repl);
 }
 
 // ---- y = prelu(bn(x)) + residual.  Every block folds the replicated statistics into
@@ -178,6 +186,7 @@ struct BnApplyArgs {
   float* out_sums;        // [REPL][2][C] statistics of y (pre-zeroed) or nullptr
   int out_nchw;           // 1: y index = n*(C*HW) + c*HW + hw (the flatten order of the reference's fc input)
   int xcd;                // 1: block -> row range in XCD-major order (bn_block_id)
+  int repl;               // replicas in use (vlsfr::g_bn_repl)
 };
 
 // FLAGS (compile time, so that the streaming loop is one straight-line block): 1 PReLU, 2 residual,
@@ -191,8 +200,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
   const float invM = 1.f / (float)a.M;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int r = 0; r < REPL; ++r) {
+#pragma unroll 8
+    for (int r = 0; r < a.repl; ++r) {
       s += a.sums[(size_t)r * 2 * C + c];
       q += a.sums[(size_t)r * 2 * C + C + c];
     }
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
       }
     }
   }
-  if (OSUMS) block_reduce_to_replica<2>(v, m, C, sh, a.out_sums);
+  if (OSUMS) block_reduce_to_replica<2>(v, m, C, sh, a.out_sums, a.repl);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,6 +319,7 @@ struct BnBwdArgs {
   const float* n_mean;
   const float* n_invstd;
   float* n_red;           // [REPL][3][C], pre-zeroed
+  int repl;               // replicas in use (vlsfr::g_bn_repl)
 };
 
 __device__ __forceinline__ float load_dy_nchw(const BnBwdArgs& a, int64_t r, int c) {
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[1][j] *= c_is[j];   // sum dz * xhat
-  block_reduce_to_replica<3>(v, m, C, sh, a.red);
+  block_reduce_to_replica<3>(v, m, C, sh, a.red, a.repl);
 }
 
 template <int FLAGS>
@@ -390,8 +400,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
   const float invM = 1.f / (float)a.M;
   for (int c = tid; c < C; c += 256) {   // fold the replicated reductions (no separate finalize launch)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int r = 0; r < REPL; ++r) {
+#pragma unroll 8
+    for (int r = 0; r < a.repl; ++r) {
       const float* p = a.red + (size_t)r * 3 * C;
       s0 += p[c];
       s1 += p[C + c];
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) nv[1][j] *= c_is2[j];
     __syncthreads();   // sh (k0, k1, k2) has been consumed by every thread
-    block_reduce_to_replica<3>(nv, m, C, sh, a.n_red);
+    block_reduce_to_replica<3>(nv, m, C, sh, a.n_red, a.repl);
   }
 }
 
@@ -778,7 +788,7 @@ int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* strea
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-                     (const u16*)x, M, C, RB, sums);
+                     (const u16*)x, M, C, RB, sums, vlsfr::g_bn_repl);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_stats");
   return VLSFR_OK;
 }
@@ -796,7 +806,7 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   BnApplyArgs a{(const u16*)x, (u16*)y, M, C, HW, RB, sums, gamma, beta, slope, (const u16*)residual, save_mean,
-                save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw, g_bn_xcd && nblk >= 16};
+                save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw, g_bn_xcd && nblk >= 16, vlsfr::g_bn_repl};
   const int flags = (slope ? 1 : 0) | (residual ? 2 : 0) | (out_sums ? 4 : 0) | (out_nchw ? 8 : 0) | (relu_after ? 16 : 0);
   const dim3 grid(nblk), block(256);
   const size_t shb = 2 * C * sizeof(float);
@@ -832,7 +842,7 @@ int vlsfr_bn_backward_chain(const void* dy, const void* x, void* dx, int64_t M, 
   bn_geom(M, C, &RB, &nblk);
   BnBwdArgs a{(const u16*)dy, (const u16*)x, (u16*)dx, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
               (const u16*)dx_add, dgamma, dbeta, dslope, dy_nchw, g_bn_xcd && nblk >= 16,
-              (const u16*)next_x, next_mean, next_invstd, next_red};
+              (const u16*)next_x, next_mean, next_invstd, next_red, vlsfr::g_bn_repl};
   const int rflags = (slope ? 1 : 0) | (dy_nchw ? 2 : 0);
   const int aflags = rflags | (dx_add ? 4 : 0) | (next_x ? 8 : 0);
   const dim3 grid(nblk), block(256);
@@ -865,7 +875,7 @@ int vlsfr_bn_backward_reduce(const void* dy, const void* x, int64_t M, int32_t C
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
   BnBwdArgs a{(const u16*)dy, (const u16*)x, nullptr, M, C, HW, RB, mean, invstd, gamma, beta, slope, red,
-              nullptr, nullptr, nullptr, nullptr, 0, g_bn_xcd && nblk >= 16, nullptr, nullptr, nullptr, nullptr};
+              nullptr, nullptr, nullptr, nullptr, 0, g_bn_xcd && nblk >= 16, nullptr, nullptr, nullptr, nullptr, vlsfr::g_bn_repl};
   const dim3 grid(nblk), block(256);
   const size_t shb = 3 * C * sizeof(float);
   if (slope) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, shb, (hipStream_t)stream, a);

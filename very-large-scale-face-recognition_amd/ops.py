@@ -42,7 +42,7 @@ def cast_weight(w_f32, rows, taps, C, Kp=None, transpose=True):
     return wb, wT
 
 
-BN_REPL = 32   # VLSFR_BN_REPL
+BN_REPL = int(_lib.lib().vlsfr_bn_repl())   # VLSFR_BN_REPL of the loaded library
 
 
 def conv2d_fwd(x, w, desc, splitk=1, out_f32=False, stats=None):
