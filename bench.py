@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (block-scaled v_mfma_scale_*_f8f6f4 forms), same table
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # per-launch HBM bytes of this round's kernels (scripts/profile_round.sh)
 
 
 def host_threads():
@@ -339,7 +340,9 @@ def main():
         dt = float(t.item())
     def collect():
         out = {}
-        for fam, name in ((0, "conv_igemm_kernel"), (1, "conv_wgrad_kernel"), (2, "head_sweep_kernel")):
+        # family 3: the input-gradient launches whose epilogue also accumulates the BatchNorm-backward reduction (a separate
+        # kernel instantiation doing more than the convolution: priced on the convolution's FLOPs only, reported apart)
+        for fam, name in ((0, "conv_igemm_kernel"), (1, "conv_wgrad_kernel"), (2, "head_sweep_kernel"), (3, "conv_igemm_bnred_kernel")):
             ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
             L.vlsfr_profile_collect.restype = ctypes.c_int
             _lib.check(L.vlsfr_profile_collect(ctypes.c_int32(fam), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
@@ -420,11 +423,11 @@ def main():
     # process, so the figure measured by rocprofv3 --pmc on this same command (profiles/) is attached
     # when the configuration matches
     try:
-        with open(os.path.join(ROOT, "profiles", "r02f_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
             pt = json.load(f)
         if pt["config"] == {"net": args.net, "batch": B, "identities": args.identities}:
             roofline["traffic"] = pt["kernels"][dom.replace("_kernel", "")]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r02f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command)" % PMC_TRAFFIC_FILE
     except (OSError, KeyError, ValueError):
         pass
     faces = world * 2 * B * args.steps

@@ -261,7 +261,7 @@ typedef struct vlsfr_conv_desc {
  * receive the per-channel sum / sum of squares of the rounded outputs — the BatchNorm statistics of
  * the following layer, fused into the epilogue. */
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk,
-                     int32_t out_f32, float* stats, void* stream);
+                     int32_t out_f32, double* stats, void* stream);
 int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream);
 /* The same with the reduction of the BatchNorm (+ PReLU) backward that consumes dx as ITS dY fused into the epilogue
  * (resnet_arcface.py:35-38 backward: bn1 behind conv1, bn2 + prelu behind conv2): x is that layer's input (bf16, shape of
@@ -299,7 +299,7 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
  *     NHWC bf16; w: fp32 [C][R*S] (the parameter's own memory); dw: fp32 [C][R*S] accumulated (+=);
  *     stats (optional): BatchNorm statistics [VLSFR_BN_REPL][2][C] of y, pre-zeroed.
  * ---------------------------------------------------------------------------------------- */
-int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, float* stats, void* stream);
+int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, double* stats, void* stream);
 int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w, void* dx, void* stream);
 int vlsfr_dwconv_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, void* stream);
 /* The same with a workspace of vlsfr_dwconv_wgrad_workspace_bytes(d) bytes: the workgroups leave per-block partial sums
@@ -315,26 +315,29 @@ int vlsfr_dwconv_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
  *    BatchNorm1d + F.normalize embedding tail (:96-98,151) and the layout/precision conversions.
  *    x, y, dy, dx, residual: bf16 [M, C] (NHWC rows), C % 8 == 0; statistics fp32.
  * ---------------------------------------------------------------------------------------- */
-/* Per-channel reductions are kept in VLSFR_BN_REPL replicated accumulators (fp32
- * [VLSFR_BN_REPL][n][C], pre-zeroed by the caller, accumulated atomically) and folded by the
- * finalize step. */
+/* Per-channel reductions are kept in VLSFR_BN_REPL replicated accumulators ([VLSFR_BN_REPL][n][C], pre-zeroed by the
+ * caller, accumulated atomically; the kernels use the first vlsfr_set_option("bn_repl") of them) and folded by the
+ * consumer.  STATISTICS (sum, sum of squares) are FLOAT64: producers accumulate fp32 deviations from a local pivot and
+ * add (sum x, sum x^2) in float64, so E[x^2] - mean^2 loses 1e-16 * mean^2, not 1e-7 * mean^2 (PyTorch's BatchNorm2d, the
+ * reference's model/resnet_arcface.py:35,37,40, uses Welford merges to the same end).  Backward reductions stay fp32
+ * (their sums are centred: dz * (x - mean)). */
 #ifndef VLSFR_BN_REPL
 #define VLSFR_BN_REPL 32
 #endif
 int vlsfr_bn_repl(void);   /* the value this library was compiled with */
-/* sums [REPL][2][C]: sum and sum of squares over the M rows of x */
-int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream);
+/* sums [REPL][2][C] float64: sum and sum of squares over the M rows of x */
+int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, double* sums, void* stream);
 /* y = prelu(bn(x)) + residual from the statistics `sums` of x (every block folds the replicas into
  * scale / shift itself; mean, invstd are saved for the backward pass; running_* get the momentum
  * update with the unbiased variance).  slope / residual / running_* may be NULL.  out_sums
- * (optional): the statistics [REPL][2][C] of y, for the next BatchNorm.  out_nchw bit 0 writes y in the
+ * (optional): the statistics [REPL][2][C] (float64) of y, for the next BatchNorm.  out_nchw bit 0 writes y in the
  * [n][c][hw] flatten order of the reference's fc input (HW = rows per image); bit 1 applies ReLU AFTER the
  * residual add, y = relu(bn(x) + residual) — the block ending of model/resnet_std.py:97-105 (needs residual,
  * no slope, no out_sums). */
-int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums,
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const double* sums,
                    const float* gamma, const float* beta, const float* slope, const void* residual,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
-                   float eps, float momentum, float* out_sums, int32_t out_nchw, void* stream);
+                   float eps, float momentum, double* out_sums, int32_t out_nchw, void* stream);
 /* dx = d(prelu(bn(x)))/dx applied to dy (+ dx_add); dgamma/dbeta/dslope are accumulated (+=);
  * red: fp32 [REPL][3][C] pre-zeroed scratch */
 int vlsfr_bn_backward(const void* dy, const void* x, void* dx, int64_t M, int32_t C, int32_t HW,

@@ -37,7 +37,7 @@ for cin, cout, k, stride, h, cnt in SHAPES:
     fl = 2.0 * B * ho * ho * cout * k * k * cin
     tf = timeit(lambda: ops.conv2d_fwd(x, w, d, stats=stats))
     td = timeit(lambda: ops.conv2d_dgrad(dy, wT, d))
-    tw = timeit(lambda: ops.conv2d_wgrad(dy, x, d, dw=dw))
+    tw = timeit(lambda: ops.conv2d_wgrad_ws(dy, x, d, dw=dw)) if os.environ.get("WS") else timeit(lambda: ops.conv2d_wgrad(dy, x, d, dw=dw))
     ms = cnt * (4 * tf + 2 * td + 2 * tw) * 1e3
     tot["fwd"] += cnt * 4 * tf * 1e3; tot["dgrad"] += cnt * 2 * td * 1e3; tot["wgrad"] += cnt * 2 * tw * 1e3
     print("%-28s %5d | %9.1f %7.0f | %9.1f %7.0f | %9.1f %7.0f | %6.2f" % ("%d %d %d %d %d" % (cin, cout, k, stride, h), cnt, tf * 1e6, fl / tf / 1e12,

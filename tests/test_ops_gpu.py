@@ -534,3 +534,48 @@ def test_dgrad_bnred_1x1_stride2_shortcut():
     got, want = red.double().sum(0).cpu().numpy(), ref.double().sum(0).cpu().numpy()
     scale = np.abs(want).max(axis=1, keepdims=True) + 1e-12
     np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)
+
+
+@pytest.mark.parametrize("ratio", [1e2, 1e3])
+def test_bn_statistics_survive_large_means(ratio):
+    """|mean| / sigma = 1e2 - 1e3 (ADVICE r01 / VERDICT r02): the batch statistics are sums of fp32 deviations from a local
+    pivot merged in float64, so E[x^2] - mean^2 does not cancel in fp32 (a single-pass fp32 sum of squares is off by ~10 % of
+    the variance at 1e3).  Checked against float64 statistics of the same bf16-rounded data: bn_stats, the fused statistics
+    of a convolution's output, and the output statistics + normalised values of bn_apply (PyTorch's BatchNorm2d, which the
+    reference uses at model/resnet_arcface.py:35,37,40, merges Welford partials to the same end)."""
+    from vlsfr_amd import ops
+    torch.manual_seed(int(ratio))
+    C, N, HW = 64, 8, 400
+    M = N * HW
+    sign = torch.where(torch.rand(C) > 0.5, 1.0, -1.0)
+    x = bf(ratio * sign + torch.randn(M, C))                       # bf16 grid spacing at 1e3 is 4: the rounded data IS the data
+    xd = x.double()
+    want_mean, want_var = xd.mean(0), xd.var(0, unbiased=False)
+    xg = x.cuda().to(torch.bfloat16)
+    sums = ops.bn_stats(xg, M, C)
+    S, Q = sums.sum(0)[0].cpu(), sums.sum(0)[1].cpu()
+    np.testing.assert_allclose((S / M).numpy(), want_mean.numpy(), rtol=1e-9)
+    np.testing.assert_allclose((Q / M - (S / M) ** 2).numpy(), want_var.numpy(), rtol=1e-6)
+    gamma, beta = torch.rand(C) + 0.5, torch.randn(C) * 0.2
+    osums = ops.new_sums(C, "cuda")
+    y, mean, invstd = ops.bn_apply(xg, M, C, HW, sums, gamma.cuda(), beta.cuda(), out_sums=osums)
+    np.testing.assert_allclose(invstd.cpu().double().numpy(), (1.0 / torch.sqrt(want_var + 1e-5)).numpy(), rtol=1e-5)
+    y_ref = (xd - want_mean) / torch.sqrt(want_var + 1e-5) * gamma.double() + beta.double()
+    close(y.reshape(M, C), bf(y_ref.float()), 1e-2)
+    yd = y.double().reshape(M, C).cpu()
+    So, Qo = osums.sum(0)[0].cpu(), osums.sum(0)[1].cpu()
+    np.testing.assert_allclose((Qo / M - (So / M) ** 2).numpy(), yd.var(0, unbiased=False).numpy(), rtol=1e-6)
+    # a convolution whose output sits far from zero: constant-ish input, positive weights
+    cin, cout, hw = 64, 128, 14
+    xi = bf(ratio / 10 + torch.randn(N, cin, hw, hw))
+    w = bf((1.0 + 0.1 * torch.randn(cout, cin, 3, 3)) / (9 * cin) * 10)
+    d = ops.ConvDesc(N, hw, hw, cin, cout, 3, 3, 1, 1)
+    wb, _ = ops.cast_weight(w.permute(0, 2, 3, 1).contiguous().cuda(), cout, 9, cin)
+    stats = ops.new_sums(cout, "cuda")
+    yc = ops.conv2d_fwd(nhwc(xi).cuda().to(torch.bfloat16), wb, d, stats=stats)
+    ycd = yc.double().reshape(-1, cout).cpu()
+    Mc = ycd.shape[0]
+    Sc, Qc = stats.sum(0)[0].cpu(), stats.sum(0)[1].cpu()
+    assert float((ycd.mean(0).abs() / ycd.std(0)).min()) > 3            # the output really is far from zero
+    np.testing.assert_allclose((Sc / Mc).numpy(), ycd.mean(0).numpy(), rtol=1e-9)
+    np.testing.assert_allclose((Qc / Mc - (Sc / Mc) ** 2).numpy(), ycd.var(0, unbiased=False).numpy(), rtol=1e-5)

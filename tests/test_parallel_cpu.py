@@ -219,18 +219,52 @@ def _spawn(target, world):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_partitioned_sgd_equals_replicated_update(world):
     """ZeRO-1 step over gloo: bucketed reduce-scatter of the gradients, update of each rank's parameter / momentum slice,
     all-gather of the slices — three steps from random parameters and per-rank gradients equal the oracle's
-    torch.optim.SGD rule on the summed gradients (parameters and momenta), on every rank."""
+    torch.optim.SGD rule on the summed gradients (parameters and momenta), on every rank.  World 8 is the node size the
+    metric is quoted on: buckets are padded to multiples of 4 x 8 elements, and a 1- or 9-element parameter leaves most
+    ranks' slices of its bucket empty."""
     for rank, err, merr, strides_ok, rs_ok, ag, mx in _spawn(_zero_worker, world):
         assert err < 1e-5 and merr < 1e-5, (rank, err, merr)
         assert strides_ok and rs_ok
         assert ag == [[float(r)] * 2 for r in range(world)] and mx == float(world - 1)
 
 
-def test_label_exchange_is_rank_ordered():
-    res = _spawn(_labels_worker, 2)
+@pytest.mark.parametrize("world", [2, 8])
+def test_label_exchange_is_rank_ordered(world):
+    res = _spawn(_labels_worker, world)
+    want_x = [v + 10 * r for r in range(world) for v in range(4)]
+    want_y = [v + 100 * r for r in range(world) for v in range(4)]
     for rank, xl, yl in res:
-        assert xl == [0, 1, 2, 3, 10, 11, 12, 13] and yl == [0, 1, 2, 3, 100, 101, 102, 103]
+        assert xl == want_x and yl == want_y
+
+
+def test_rehearsal_stand_ins_have_the_collectives_shapes():
+    """parallel.RehearsalDist / RehearsalComm (bench.py --rehearse-world: rank 0 of W in one process): every stand-in returns
+    what the real collective returns in shape and dtype, own data in rank 0's position, and the drawn labels of the other
+    ranks follow main.py:53-60 (an id half shared between the two views)."""
+    from vlsfr_amd.parallel import RehearsalComm, RehearsalDist
+    W, B = 8, 6
+    d = RehearsalDist(W, 1000, seed=1)
+    c = RehearsalComm(W)
+    assert d.get_world_size() == W and d.get_rank() == 0 and c.world == W and c.rank == 0
+    lab = torch.stack([torch.arange(B), torch.arange(B) + 50])
+    out = [torch.empty_like(lab) for _ in range(W)]
+    d.all_gather(out, lab)
+    assert torch.equal(out[0], lab)
+    for r in range(1, W):
+        assert out[r].shape == (2, B) and torch.equal(out[r][0, :B // 2], out[r][1, :B // 2]) and int(out[r].max()) < 1000
+        assert len(set(out[r][0, :B // 2].tolist())) == B // 2
+    t = torch.randn(B, 5)
+    g = c.all_gather(t)
+    assert g.shape == (W, B, 5) and torch.equal(g[0], t) and torch.equal(g[3], t.roll(3, 0))
+    assert torch.equal(c.reduce_scatter_rows(torch.arange(W * 2 * 3.0).reshape(W * 2, 3)), torch.arange(6.0).reshape(2, 3))
+    flat, shard = torch.zeros(W * 4), torch.ones(4)
+    c.all_gather_into(flat, shard)
+    assert flat[:4].tolist() == [1.0] * 4 and float(flat[4:].abs().sum()) == 0.0
+    o = torch.empty(4)
+    c.reduce_scatter_sum(o, torch.arange(32.0))
+    assert o.tolist() == [0.0, 1.0, 2.0, 3.0]
+    assert c.all_reduce_max(t) is t and c.all_reduce_sum(t) is t and c.broadcast(t) is t

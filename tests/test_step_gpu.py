@@ -471,13 +471,16 @@ def test_fp8_class_matmul_in_the_whole_step():
         m.head_dtype = dtype
         rng = np.random.default_rng(5)
         B = 32
-        x = common.images_from_u8(common.synth_images_u8(rng, B)).cuda()
-        y = common.images_from_u8(common.synth_images_u8(rng, B)).cuda()
         ids = rng.choice(6000, size=B // 2, replace=False)
         xl = torch.from_numpy(np.concatenate([ids, rng.integers(0, 6000, B - B // 2)]).astype(np.int64))
         yl = torch.from_numpy(np.concatenate([ids, rng.integers(0, 6000, B - B // 2)]).astype(np.int64))
         losses = []
         for it in range(2):               # second step: the pool rows written by the first are swept from the shadow
+            # fresh images of the same identities every step: with the SAME images (and no optimizer step in between) the
+            # probe embedding equals the pool row the gallery net wrote for it, cos = 1, and ArcFace's sqrt(1 - cos^2) has no
+            # clamp (ffc.py:100-103) — the forward pass is reproducible enough now (float64 statistics) to hit it
+            x = common.images_from_u8(common.synth_images_u8(rng, B)).cuda()
+            y = common.images_from_u8(common.synth_images_u8(rng, B)).cuda()
             m.zero_grad()
             loss = m(x, y, xl, yl)
             loss.backward()

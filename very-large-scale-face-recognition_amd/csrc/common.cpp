@@ -1,3 +1,7 @@
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <hip/hip_runtime_api.h>
 
 #include "common_host.h"
@@ -6,6 +10,24 @@ namespace vlsfr {
 char* error_buffer() {
   static thread_local char buf[512] = {0};
   return buf;
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel; launches come from several host threads
+// (forward on the caller's thread, backward on autograd's): one mutex-guarded table keyed by (device, kernel) remembers the
+// largest size set so far, so the attribute call happens once per device and kernel (or when a launch needs more).
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* who) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(VLSFR_EHIP, "%s: hipGetDevice: %s", who, hipGetErrorString(e));
+  std::lock_guard<std::mutex> lk(mu);
+  int& cur = done[std::make_pair(dev, kernel)];
+  if (bytes > cur) {
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(VLSFR_EHIP, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+    cur = bytes;
+  }
+  return VLSFR_OK;
 }
 }  // namespace vlsfr
 

@@ -17,4 +17,7 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// per-device, thread-safe hipFuncSetAttribute(MaxDynamicSharedMemorySize) cache (common.cpp)
+int ensure_dynamic_lds(const void* kernel, int bytes, const char* who);
+
 }  // namespace vlsfr

@@ -32,18 +32,42 @@ namespace vlsfr {
 struct ProfRec {
   hipEvent_t a, b;
   double work;
-  int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep
+  int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep, 3: conv_igemm with the fused BN-backward reduction
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;   // forward and backward passes are enqueued from different host threads
+// The events of the brackets come from a pool created by vlsfr_profile_enable on ITS caller's thread, before any bracketed
+// launch: no hipEventCreate / hipEventDestroy on the launch path (which runs on the caller's thread for forward passes and
+// on autograd's for backward passes).  Under rocprofv3 --pmc the per-launch create/destroy from two threads ended in a
+// segmentation fault of the profiled process (round 2, gpurun_out/prof_r02f.log); with the pool the same pass completes.
+static std::vector<hipEvent_t> g_prof_pool;
+static size_t g_prof_next = 0;   // guarded by g_prof_mu
+static int prof_pool_reserve(size_t n_events) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  while (g_prof_pool.size() < n_events) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return -1;
+    g_prof_pool.push_back(e);
+  }
+  return 0;
+}
+static int g_prof_pool_on = 1;   // "prof_pool": 0 = round 2's per-launch hipEventCreate (kept to reproduce the --pmc failure)
 ProfScope::ProfScope(hipStream_t s, int fam, double w) : st(s), on(g_prof_on), family(fam), work(w) {
   if (!on) return;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
-    on = false;
-    return;
+  if (!g_prof_pool_on) {
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) on = false;
+  } else {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_next + 2 + 128 > g_prof_pool.size()) {   // pool exhausted (its last 128 events belong to the overhead probe): unbracketed
+      on = false;
+      return;
+    }
+    a = g_prof_pool[g_prof_next];
+    b = g_prof_pool[g_prof_next + 1];
+    g_prof_next += 2;
   }
-  (void)hipEventRecord(a, st);
+  if (on) (void)hipEventRecord(a, st);
 }
 ProfScope::~ProfScope() {
   if (!on) return;
@@ -94,7 +118,7 @@ struct ConvArgs {
   int mode;          // 0: forward gather, 1: input-gradient gather
   int splitk;
   int out_f32;
-  float* stats;      // optional [VLSFR_BN_REPL][2][Mrows] BatchNorm statistics of the rounded output
+  double* stats;     // optional [VLSFR_BN_REPL][2][Mrows] float64 BatchNorm statistics (sum, sum of squares) of the rounded output
   long long* trace;  // diagnostics: per-phase clock stamps of waves 0 and 4 of one workgroup (vlsfr_conv_trace), or nullptr
   int gx = 0, gy = 0, xcd = 0;   // xcd != 0: launched as a 1-D grid of gx * gy * splitk workgroups in XCD-major order (xcd_major_id)
   // Parity-class launch of a stride-2 input gradient (vlsfr_conv2d_dgrad): the input positions (2 h' + ph, 2 w' + pw) of one
@@ -344,12 +368,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     }
     return;
   }
-  // bf16 output; the BatchNorm statistics are taken from the ROUNDED values (what the consumer reads)
-  float cs[MT][4], cq[MT][4];
+  // bf16 output; the BatchNorm statistics are taken from the ROUNDED values (what the consumer reads), as sums of
+  // DEVIATIONS from a pivot: the value of the first pixel of this wave's pixel range for the channel (lane r16 = 0 of the
+  // 16-lane row holds it; one ds_bpermute per channel hands it to the row).  Deviations are of the order of the spread
+  // whatever the mean, so fp32 is enough up to the workgroup level; (sum x, sum x^2) are formed and added in float64 there.
+  float cs[MT][4], cq[MT][4], cp[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = 0.f;
+    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = cp[i][e] = 0.f;
+  if constexpr (!RED) {
+    if (a.stats) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cp[i][e] = __shfl((float)(__bf16)acc[i][0][e], (tid & 63) & 48, 64);
+    }
+  }
   // 16-byte stores: rows h and h ^ 1 of the MFMA layout hold channels 4h..4h+3 and 4h+4..4h+7 of the same
   // pixel, so v_permlane16_swap hands the even rows both halves of pixel tile j and the odd rows both
   // halves of tile j + 1 -- 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail of a workgroup
@@ -401,7 +436,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
           for (int e = 0; e < 4; ++e) {
             o[e] = (__bf16)acc[i][j][e];
             if constexpr (!RED) {   // forward statistics (an input-gradient launch with the fused reduction has none)
-              const float f = ok ? (float)o[e] : 0.f;
+              const float f = ok ? (float)o[e] - cp[i][e] : 0.f;
               cs[i][e] += f;
               cq[i][e] += f * f;
             }
@@ -454,17 +489,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     }
   };
   if (a.stats) {   // fused BatchNorm statistics of the rounded output (forward launches)
-    float keep[2][NR];
+    float keep[3][NR];   // sum of deviations, sum of squared deviations, pivot
 #pragma unroll
-    for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = 0.f;
+    for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = keep[2][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         fold(cs[i][e], i, e, keep[0]);
         fold(cq[i][e], i, e, keep[1]);
+        if (r16 == (i & 3) * 4 + e) keep[2][i >> 2] = cp[i][e];   // the row shares one pivot: no sum
       }
-    flush(std::integral_constant<int, 2>{}, keep, a.stats);
+    float* red = red_lds;   // [WN][3][BM]
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ni = MT - 4 * r < 4 ? MT - 4 * r : 4;
+      if (r16 < ni * 4) {
+        const int ml = wm * (BM / WM) + (4 * r + (r16 >> 2)) * 16 + 4 * h + (r16 & 3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) red[(wn * 3 + q) * BM + ml] = keep[q][r];
+      }
+    }
+    __syncthreads();
+    double* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.Mrows;
+    for (int ml = tid; ml < BM; ml += NW * 64) {
+      double S = 0.0, Q = 0.0;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) {
+        int nv = P - (p0 + w * (BN / WN));                       // valid pixels of pixel range w
+        nv = nv < 0 ? 0 : (nv > BN / WN ? BN / WN : nv);
+        const double n = (double)nv, sd = (double)red[(w * 3 + 0) * BM + ml], qd = (double)red[(w * 3 + 1) * BM + ml],
+                     pv = (double)red[(w * 3 + 2) * BM + ml];
+        S += n * pv + sd;
+        Q += qd + 2.0 * pv * sd + n * pv * pv;
+      }
+      if (m0 + ml < a.Mrows) {
+        atomicAdd(dst + m0 + ml, S);
+        atomicAdd(dst + (size_t)a.Mrows + m0 + ml, Q);
+      }
+    }
   }
   if constexpr (RED) {
     // BatchNorm-backward reduction fused into an input-gradient launch (ConvArgs::red_x).  The x tile [BN pixels][BM
@@ -1469,8 +1532,41 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   if (a.dbg & 1) return;
-  // ---- epilogue: D[row = cout 4h + e][col = ci r16], fp32 atomics into the gradient
+  // ---- epilogue: D[row = cout 4h + e][col = ci r16]
   const int K = a.R * a.S * a.C;
+  if (a.partial) {
+    // Deterministic path: this slice's tile goes to its slab with plain stores, summed later in a fixed order
+    // (wgrad_reduce_kernel).  The MFMA layout gives a lane 4 rows x 1 column per accumulator register — 64-byte row
+    // segments per wave-instruction if stored as it stands (measured 532 vs 605 TFLOP/s for the atomics); the tile is
+    // transposed through the LDS the ring no longer needs ([BM][BN] fp32, 16-column groups XOR-swizzled with bit 2 of
+    // the row: the four rows a wave-instruction writes land on two bank halves), and written out as whole 512-byte
+    // rows, 16 bytes per lane.
+    static_assert(BM * BN * 4 <= NST * STAGE, "the transposed tile takes the ring's LDS");
+    float* T = (float*)smem;
+    __syncthreads();   // every wave has read its last fragments
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = wm * (BM / 2) + i * 16 + 4 * h + e;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = wn * (BN / 2) + j * 16 + r16;
+          T[row * BN + (col ^ (((row >> 2) & 1) << 4))] = acc[i][j][e];
+        }
+      }
+    __syncthreads();
+    float* slab = a.partial + (size_t)bz * a.Cout * K + (size_t)tap * a.C + c0;
+    constexpr int QPR = BN / 4;   // 16-byte chunks per row
+    for (int idx = tid; idx < BM * QPR; idx += 256) {
+      const int row = idx / QPR, q = idx - row * QPR;
+      const int m = m0 + row, c = 4 * q;
+      if (m < a.Cout && (TPT > 1 || c0 + c < a.C))
+        *(f32x4*)(slab + (size_t)m * K + c) = *(const f32x4*)(T + row * BN + ((q ^ (((row >> 2) & 1) << 2)) << 2));
+    }
+    return;
+  }
+  // fp32 atomics into the gradient
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -1480,10 +1576,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = c0 + wn * (BN / 2) + j * 16 + r16;
-        if (TPT > 1 || c < a.C) {
-          if (a.partial) a.partial[(size_t)bz * a.Cout * K + (size_t)m * K + tap * a.C + c] = acc[i][j][e];
-          else atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
-        }
+        if (TPT > 1 || c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
       }
     }
   }
@@ -1552,13 +1645,8 @@ int conv_check(const vlsfr_conv_desc* d, const char* who) {
 template <int BM, int BN, int BK, int NST, int NW = 4, bool PP = false, bool SWP = false, bool RED = false>
 int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   constexpr int lds = NST * (BM + BN) * BK * 2;
-  static bool attr_set = false;
   auto kern = conv_igemm_glds_kernel<BM, BN, BK, NST, NW, PP, SWP, RED>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return hip_fail(e, "conv_igemm_glds: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_glds")) return rc;
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
   ConvArgs b = a;
   const size_t nwg = (size_t)grid.x * grid.y * grid.z;
@@ -1575,13 +1663,8 @@ int launch_igemm_halo(const ConvArgs& a, int P, hipStream_t st) {
   const int PR = ((128 + 2 * a.W + 2) + 7) & ~7;
   const int npatch = a.C > 64 ? 2 : 1;
   const int lds = 2 * BM * 128 + npatch * PR * 128 + 1024;
-  static int attr_lds = 0;
   auto kern = conv_igemm_halo_kernel<BM, PI>;
-  if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return hip_fail(e, "conv_igemm_halo: hipFuncSetAttribute");
-    attr_lds = lds;
-  }
+  if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_halo")) return rc;
   dim3 grid((P + 127) / 128, (a.Mrows + BM - 1) / BM, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, PR, npatch);
   return VLSFR_OK;
@@ -1611,7 +1694,7 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   const double alg_k = a.tap_mask ? (double)__builtin_popcount(a.tap_mask) * a.C   // parity-class launch: the taps it walks
                        : (a.mode == 0 && a.R == 1 && a.S == 1 && (a.C == 32 || a.C == 160)) ? (a.C == 32 ? 27.0 : 147.0)
                                                                                               : (double)a.R * a.S * a.C;
-  ProfScope prof(st, 0, 2.0 * alg_pos * (double)a.Mrows * alg_k);
+  const double alg_flops = 2.0 * alg_pos * (double)a.Mrows * alg_k;
   // tile choice: the 128x128 tile unless the channel count or the pixel count is small
   const long wg_big = (long)((P + 127) / 128) * ((a.Mrows + 127) / 128) * a.splitk;
   const bool glds_ok = g_use_glds && a.C % 64 == 0 && a.R * a.S <= 9 && (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30) &&
@@ -1619,6 +1702,14 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   const bool halo_ok = (g_use_halo == 2 || (g_use_halo == 1 && a.Mrows < 128)) && glds_ok && !a.tap_mask && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.splitk == 1 &&
                        !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.W <= 112 && a.H >= 2 && P >= 128;
   if (a.tap_mask && !glds_ok) return fail(VLSFR_EINVAL, "conv_igemm: a parity-class launch needs the LDS-DMA kernel");
+  // the default LDS-DMA variant's per-shape choices (decided here so that the timing bracket knows its family)
+  const bool variant_default = g_use_glds == VLSFR_DEFAULT_CONV_VARIANT;
+  const bool big_tile = a.Mrows >= 128 && wg_big >= g_small_tile_wgs;
+  const bool tile256_here = glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * 160 &&
+                            P <= 256 * 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
+  const bool red_here = glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
+                        (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) && (g_bnred_all || (big_tile && !a.cls));
+  ProfScope prof(st, red_here ? 3 : 0, alg_flops);
   if (halo_ok) {
     int rc;
     const bool pi2 = (128 + 2 * a.W + 2 + 7) / 8 > 32;
@@ -1662,20 +1753,16 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
     else if (g_use_glds == 6) rc = big ? launch_igemm_glds<128, 128, 32, 3>(a, P, st) : launch_igemm_glds<64, 128, 32, 3>(a, P, st);
     else if (g_use_glds == 7) rc = big ? launch_igemm_glds<128, 128, 32, 2>(a, P, st) : launch_igemm_glds<64, 128, 32, 2>(a, P, st);
     else if (g_use_glds == 4) rc = big ? launch_igemm_glds<128, 128, 32, 5>(a, P, st) : launch_igemm_glds<64, 128, 32, 5>(a, P, st);
-    else if (g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * 160 && P <= 256 * 256 && !(a.red_x && g_tile256 == 2) &&
-             !g_bnred_all) {
-      // 256-channel layers with 160 - 256 pixel tiles of 256 (ir100 at batch 256: the 58 + 58 convolutions at 14 x 14, 55 % of the
-      // FLOPs): one 256 x 256 tile per CU, 8 waves.  The LDS-DMA path delivers ~31 B / clk / CU from L2 and bounds the
-      // 128 x 128 tile (64 FLOP per byte) at half the MFMA rate; the 256 x 256 tile needs half the bytes per FLOP, and its
-      // 196 tiles run in ONE round instead of 784 tiles in 1.53 rounds on 512 slots (scripts/conv_shapes.py: 73.4 vs 81.7 us).
+    else if (tile256_here) {
+      // 256-channel layers with 160 - 256 pixel tiles of 256 (ir100 at batch 256: the 58 forward convolutions at 14 x 14): one
+      // 256 x 256 tile per CU, 8 waves, ONE round of 196 tiles instead of 784 tiles of 128 x 128 in 1.53 rounds on 512 slots
+      // (scripts/conv_shapes.py: 73.4 vs 81.7 us; at equal fill the two tiles run at the same rate, 995 vs 954 TFLOP/s).
       // "tile256": 0 off, 1 forward + input gradient (the fused BatchNorm-backward reduction has no 256 x 256 form: that
-      // launch then takes the stand-alone reduction kernel), 2 forward only
+      // launch then takes the stand-alone reduction kernel), 2 forward only (default)
       rc = launch_igemm_glds<256, 256, 64, 2, 8>(a, P, st);
-    }
-    else if (a.red_x && !a.out_f32 && a.splitk == 1 && (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) &&
-             (g_bnred_all || (big && !a.cls))) {
+    } else if (red_here) {
       // measured per launch at batch 256 (scripts/dgrad_bnred_micro.py): the fused epilogue beats "plain launch + stand-alone
-      // reduction kernel" on the 128 x 128 tiles of the stride-1 layers (128 / 256 / 512 channels: 7 - 10 us saved of 20 - 30)
+      // reduction kernel" on the 128 x 128 tiles of the stride-1 layers (128 / 256 / 512 channels: 4 - 9 us saved of 20 - 30)
       // and loses on the 64-channel layers (6 - 12 tile rounds per launch: the epilogue is paid per tile) and on the four
       // parity-class launches of a stride-2 layer; "bnred_all" = 1 forces it everywhere (tests)
       rc = big ? launch_igemm_glds<128, 128, 64, 2, 4, false, false, true>(a, P, st)
@@ -1700,7 +1787,10 @@ int bn_red_fallback(const vlsfr_conv_desc* d, const void* dx, const vlsfr_bn_red
 
 extern "C" {
 
-void vlsfr_profile_enable(int32_t on) { vlsfr::g_prof_on = on != 0; }
+void vlsfr_profile_enable(int32_t on) {
+  if (on && vlsfr::prof_pool_reserve(1 << 16) != 0) on = 0;   // 32 768 brackets (ir100: ~2 700 launches of the timed families per step)
+  vlsfr::g_prof_on = on != 0;
+}
 
 int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "wgrad_round_up")) {
@@ -1734,6 +1824,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   if (name && !strcmp(name, "bn_repl")) {
     if (value < 1 || value > VLSFR_BN_REPL) return fail(VLSFR_EINVAL, "vlsfr_set_option: bn_repl must be in [1, %d]", VLSFR_BN_REPL);
     vlsfr::g_bn_repl = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "prof_pool")) {
+    vlsfr::g_prof_pool_on = value != 0;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "tile256")) {
@@ -1802,6 +1896,7 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
   if (!total_ms || !total_flops || !launches) return fail(VLSFR_EINVAL, "vlsfr_profile_collect: null argument");
   double ms = 0, fl = 0;
   int64_t n = 0;
+  std::lock_guard<std::mutex> lk(vlsfr::g_prof_mu);
   for (auto& r : vlsfr::g_prof) {
     if (r.family != family) continue;
     hipError_t e = hipEventSynchronize(r.b);
@@ -1824,34 +1919,31 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
 double vlsfr_profile_event_overhead_us(void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int N = 64;
-  hipEvent_t a[N], b[N];
-  for (int i = 0; i < N; ++i)
-    if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return 0.0;
+  if (vlsfr::prof_pool_reserve(1 << 16) != 0) return 0.0;
+  std::lock_guard<std::mutex> lk(vlsfr::g_prof_mu);
+  if (vlsfr::g_prof_pool.size() < 2 * (size_t)N) return 0.0;
+  hipEvent_t* ev = vlsfr::g_prof_pool.data() + (vlsfr::g_prof_pool.size() - 2 * N);   // the pool's last events: never handed to a bracket while this runs
   for (int i = 0; i < N; ++i) {
-    (void)hipEventRecord(a[i], st);
-    (void)hipEventRecord(b[i], st);
+    (void)hipEventRecord(ev[2 * i], st);
+    (void)hipEventRecord(ev[2 * i + 1], st);
   }
   (void)hipStreamSynchronize(st);
   double sum = 0.0;
   for (int i = 0; i < N; ++i) {
     float t = 0.f;
-    if (hipEventElapsedTime(&t, a[i], b[i]) == hipSuccess) sum += t;
-    (void)hipEventDestroy(a[i]);
-    (void)hipEventDestroy(b[i]);
+    if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) == hipSuccess) sum += t;
   }
   return sum / N * 1e3;
 }
 
-void vlsfr_profile_reset(void) {
-  for (auto& r : vlsfr::g_prof) {
-    (void)hipEventDestroy(r.a);
-    (void)hipEventDestroy(r.b);
-  }
+void vlsfr_profile_reset(void) {   // the events go back to the pool (nothing is destroyed)
+  std::lock_guard<std::mutex> lk(vlsfr::g_prof_mu);
   vlsfr::g_prof.clear();
+  vlsfr::g_prof_next = 0;
 }
 
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk, int32_t out_f32,
-                     float* stats, void* stream) {
+                     double* stats, void* stream) {
   int rc = conv_check(d, "vlsfr_conv2d_fwd");
   if (rc) return rc;
   if (!x || !w || !y) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd: null buffer");
@@ -2042,12 +2134,7 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
     if (glds) {                                                                                        \
       constexpr int lds_ = 2 * 64 * (BM_ + BN_) * 2;                                                   \
       auto kern_ = conv_wgrad_glds_kernel<BM_, BN_, 64, 2, 1>;                                            \
-      static bool attr_ = false;                                                                       \
-      if (!attr_) {                                                                                    \
-        hipError_t e_ = hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_); \
-        if (e_ != hipSuccess) return hip_fail(e_, "conv_wgrad_glds: hipFuncSetAttribute");             \
-        attr_ = true;                                                                                  \
-      }                                                                                                \
+      if (int rc_ = ensure_dynamic_lds((const void*)kern_, lds_, "conv_wgrad_glds")) return rc_;       \
       hipLaunchKernelGGL(kern_, grid, dim3(256), lds_, st, a);                                         \
     } else if (KT == 64) hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 64>), grid, dim3(256), 0, st, a); \
     else hipLaunchKernelGGL((conv_wgrad_kernel<BM_, BN_, 32>), grid, dim3(256), 0, st, a);               \
@@ -2055,12 +2142,7 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
   if (BN == 192) {
     constexpr int lds_ = 2 * 64 * (64 + 192) * 2;
     auto kern_ = conv_wgrad_glds_kernel<64, 192, 64, 2, 3>;
-    static bool attr_ = false;
-    if (!attr_) {
-      hipError_t e_ = hipFuncSetAttribute((const void*)kern_, hipFuncAttributeMaxDynamicSharedMemorySize, lds_);
-      if (e_ != hipSuccess) return hip_fail(e_, "conv_wgrad_glds: hipFuncSetAttribute");
-      attr_ = true;
-    }
+    if (int rc_ = ensure_dynamic_lds((const void*)kern_, lds_, "conv_wgrad_glds")) return rc_;
     hipLaunchKernelGGL(kern_, grid, dim3(256), lds_, st, a);
   } else if (BM == 128 && BN == 128) VLSFR_WGRAD(128, 128);
   else if (BM == 128) VLSFR_WGRAD(128, 64);

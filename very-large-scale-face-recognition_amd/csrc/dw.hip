@@ -36,7 +36,8 @@ struct DwArgs {
   u16* out;          // forward: y [N,Ho,Wo,C]; dgrad: dx [N,H,W,C]
   int N, H, W, C, Ho, Wo, k, stride, pad;
   int dgrad;         // 0 forward, 1 input gradient
-  float* stats;      // forward only: [REPL][2][C] or nullptr
+  double* stats;     // forward only: [REPL][2][C] float64 (sum, sum of squares) or nullptr.  Block partials are plain fp32 sums
+                     // (a few thousand outputs each), the accumulation across blocks is float64
   int repl = 1;      // replicas in use (vlsfr::g_bn_repl)
 };
 
@@ -120,8 +121,8 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
+    double* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], (double)sh[i]);
   }
 }
 
@@ -161,9 +162,9 @@ __global__ __launch_bounds__(256) void dw_global_fwd_kernel(DwArgs a) {
     a.out[(size_t)n * a.C + c] = __builtin_bit_cast(u16, yb);
     if (a.stats) {
       const float f = (float)yb;
-      float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
-      atomicAdd(&dst[c], f);
-      atomicAdd(&dst[a.C + c], f * f);
+      double* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
+      atomicAdd(&dst[c], (double)f);
+      atomicAdd(&dst[a.C + c], (double)f * (double)f);
     }
   }
 }
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256) void dw3_kernel(DwArgs a) {
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
+    double* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], (double)sh[i]);
   }
 }
 
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(256) void dw3_strip_kernel(DwArgs a) {
       }
     }
     __syncthreads();
-    float* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], sh[i]);
+    double* dst = a.stats + (size_t)(blockIdx.x % a.repl) * 2 * a.C;
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) atomicAdd(&dst[i], (double)sh[i]);
   }
 }
 
@@ -665,7 +666,7 @@ int dw_blocks(int64_t P, int C) {
 
 extern "C" {
 
-int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, float* stats, void* stream) {
+int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, double* stats, void* stream) {
   int rc = dw_check(d, "vlsfr_dwconv_fwd");
   if (rc) return rc;
   if (!x || !w || !y) return fail(VLSFR_EINVAL, "vlsfr_dwconv_fwd: null buffer");

@@ -32,7 +32,7 @@ struct Bn {
   int p_w, p_b;      // parameter indices (gamma, beta)
   int p_slope;       // PReLU parameter index or -1
   int run;           // index of the (running_mean, running_var) pair
-  size_t off_sums;   // ctx: fp32 [REPL][2][C] statistics accumulators (zeroed at forward start)
+  size_t off_sums;   // ctx: float64 [REPL][2][C] statistics accumulators (zeroed at forward start)
   size_t off_mean;   // ctx: fp32 [C]
   size_t off_invstd; // ctx: fp32 [C]
   size_t off_scale;  // ctx: fp32 [C]
@@ -172,7 +172,7 @@ int build(vlsfr_iresnet* n) {
 
   // ---- ctx layout: statistics first (one memset clears every sums slot), then activations
   n->sums_begin = n->ctx_bytes;
-  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * b.C * 4); };
+  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * b.C * 8); };
   sums(n->stem_bn);
   for (auto& b : n->blocks) {
     sums(b.bn1);
@@ -276,11 +276,11 @@ Scratch carve(const vlsfr_iresnet* n, void* scratch) {
   } while (0)
 
 // statistics (already accumulated by the producer of x) -> scale/shift, then y = prelu(bn(x)) + residual
-int bn_forward(const Bn& b, const void* x, void* y, int64_t M, int HW, const void* residual, float* out_sums,
+int bn_forward(const Bn& b, const void* x, void* y, int64_t M, int HW, const void* residual, double* out_sums,
                int out_nchw, const float* const* params, float* const* running, char* ctx, void* st) {
   float* rm = running ? running[2 * b.run] : nullptr;
   float* rv = running ? running[2 * b.run + 1] : nullptr;
-  return vlsfr_bn_apply(x, y, M, b.C, HW, (const float*)(ctx + b.off_sums), params[b.p_w], params[b.p_b],
+  return vlsfr_bn_apply(x, y, M, b.C, HW, (const double*)(ctx + b.off_sums), params[b.p_w], params[b.p_b],
                         b.p_slope >= 0 ? params[b.p_slope] : nullptr, residual, (float*)(ctx + b.off_mean),
                         (float*)(ctx + b.off_invstd), rm, rv, BN_EPS, BN_MOM, out_sums, out_nchw, st);
 }
@@ -304,7 +304,7 @@ int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M,
 int forward_block(const vlsfr_iresnet* n, int k, const char* cur, const float* const* params, float* const* running, char* ctx,
                   const char* wc, const Scratch& sc, void* st) {
   const int B = n->B;
-  auto sums_of = [&](const Bn& b) { return (float*)(ctx + b.off_sums); };
+  auto sums_of = [&](const Bn& b) { return (double*)(ctx + b.off_sums); };
   const Block& b = n->blocks[k];
   const Bn& next_bn = (size_t)k + 1 < n->blocks.size() ? n->blocks[k + 1].bn1 : n->bn_last;
   const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
@@ -419,7 +419,7 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
   hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward: memset: %s", hipGetErrorString(e));
   const int B = n->B, S = n->HW0;
-  auto sums_of = [&](const Bn& b) { return (float*)(ctx + b.off_sums); };
+  auto sums_of = [&](const Bn& b) { return (double*)(ctx + b.off_sums); };
   // Every BatchNorm's batch statistics are accumulated by the kernel that PRODUCES its input (conv
   // epilogue or the previous bn_apply), so no tensor is read just to be averaged.
   // stem (resnet_arcface.py:140-142)
@@ -543,7 +543,7 @@ int vlsfr_iresnet_forward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1,
   const int64_t Min = (int64_t)n->B * first.H * first.W;
   if (e == hipSuccess) e = hipMemcpyAsync(cur, x_in, (size_t)Min * first.cin * 2, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward_blocks: %s", hipGetErrorString(e));
-  RUN(vlsfr_bn_stats(cur, Min, first.cin, (float*)(ctx + first.bn1.off_sums), st));
+  RUN(vlsfr_bn_stats(cur, Min, first.cin, (double*)(ctx + first.bn1.off_sums), st));
   for (int k = k0; k < k1; ++k) {
     RUN(forward_block(n, k, cur, params, running, ctx, wc, sc, st));
     cur = ctx + n->blocks[k].out;

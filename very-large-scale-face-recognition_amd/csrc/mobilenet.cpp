@@ -130,7 +130,7 @@ int build(vlsfr_mobilenet* n) {
   n->l1_wT = n->take_w((size_t)n->D * 512 * 2);
 
   n->sums_begin = n->ctx_bytes;
-  for (auto& u : n->units) u.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * u.d.Cout * 4);
+  for (auto& u : n->units) u.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * u.d.Cout * 8);
   n->off_fc = n->take_ctx((size_t)n->B * n->D * 4);
   n->off_zero_bias = n->take_ctx((size_t)n->D * 4);
   n->sums_end = n->ctx_bytes;
@@ -198,7 +198,7 @@ Scratch carve(const vlsfr_mobilenet* n, void* scratch) {
 int forward_unit(const vlsfr_mobilenet* n, int k, const float* x_nchw, const float* const* params, float* const* running,
                  char* ctx, const char* wc, void* st) {
   const Unit& u = n->units[k];
-  float* sums = (float*)(ctx + u.off_sums);
+  double* sums = (double*)(ctx + u.off_sums);
   const char* in = u.in_unit >= 0 ? ctx + n->units[u.in_unit].a : nullptr;
   if (u.kind == STEM) {
     RUN(vlsfr_stem_im2col(x_nchw, ctx + n->off_cols, n->B, n->S, n->S, 2, st));

@@ -116,19 +116,87 @@ __device__ __forceinline__ void block_reduce_to_replica(float (&v)[NV][8], const
   for (int i = tid; i < NV * C; i += 256) atomicAdd(&dst[i], sh[i]);
 }
 
+// ---- BatchNorm statistics (sum, sum of squares per channel) without the E[x^2] - mean^2 cancellation.
+// A thread accumulates DEVIATIONS from the first value it sees per channel (fp32: the deviations are of the order of the
+// spread, whatever the mean), turns them into (sum x, sum x^2) in float64 — exact to ~1e-16 of the mean^2 term — and from
+// there on everything is added in float64: lanes that share a channel group, the block's LDS image, the replicated
+// accumulators in global memory (global_atomic_add_f64), the fold in the consumer.  What is left of the cancellation is
+// 1e-16 * mean^2 against the variance instead of 1e-7 * mean^2 (|mean| / sigma = 1e3: 1e-10 instead of 0.1).
+struct StatAcc {
+  float s[8], q[8], p[8];
+  int n;
+  __device__ __forceinline__ void init() {
+    n = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = p[j] = 0.f;
+  }
+  __device__ __forceinline__ void add(const bf8& v) {
+    if (n == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[j] = v.get(j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = v.get(j) - p[j];
+      s[j] += d;
+      q[j] += d * d;
+    }
+    ++n;
+  }
+};
+
+// sums of the block into out[rep][2][C] (float64); shd: 2 * C doubles of LDS
+__device__ __forceinline__ void block_stats_to_replica(const StatAcc& t, const RowMap& m, int C, double* shd, double* out, int repl) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * C; i += 256) shd[i] = 0.0;
+  __syncthreads();
+  double S[8], Q[8];
+  const double n = m.active ? (double)t.n : 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double p = (double)t.p[j], s = m.active ? (double)t.s[j] : 0.0, q = m.active ? (double)t.q[j] : 0.0;
+    S[j] = n * p + s;
+    Q[j] = q + 2.0 * p * s + n * p * p;
+  }
+  const bool pow2 = (m.cg & (m.cg - 1)) == 0;
+  if (pow2 && m.cg <= 32) {   // lanes l, l + cg, l + 2 cg, ... hold the same channel group
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int o = 32; o >= m.cg; o >>= 1) {
+        S[j] += __shfl_xor(S[j], o, 64);
+        Q[j] += __shfl_xor(Q[j], o, 64);
+      }
+    if ((tid & 63) < m.cg) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&shd[m.col * 8 + j], S[j]);
+        atomicAdd(&shd[C + m.col * 8 + j], Q[j]);
+      }
+    }
+  } else if (m.active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&shd[m.col * 8 + j], S[j]);
+      atomicAdd(&shd[C + m.col * 8 + j], Q[j]);
+    }
+  }
+  __syncthreads();
+  double* dst = out + (size_t)(blockIdx.x % repl) * 2 * C;
+  for (int i = tid; i < 2 * C; i += 256) atomicAdd(&dst[i], shd[i]);
+}
+
 __device__ __forceinline__ int rows_per_block(int C, int rpb) {
   int rb = 32768 / (C * 2);
   if (rb < rpb) rb = rpb;
   return (rb / rpb) * rpb;
 }
 
-// ---- statistics of x[M, C]: sums[REPL][2][C] (sum, sum of squares), pre-zeroed
-__global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, int C, int RB, float* sums, int repl) {
-  extern __shared__ float sh[];
+// ---- statistics of x[M, C]: sums[REPL][2][C] float64 (sum, sum of squares), pre-zeroed
+__global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, int C, int RB, double* sums, int repl) {
+  extern __shared__ double shd[];
   const RowMap m = row_map(C);
-  float v[2][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[0][j] = v[1][j] = 0.f;
+  StatAcc t;
+  t.init();
   const int64_t r0 = (int64_t)blockIdx.x * RB;
   const int64_t r1 = r0 + RB < M ? r0 + RB : M;
   if (m.active) {
@@ -142,16 +210,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const u16* x, int64_t M, 
 #pragma unroll
       for (int u = 0; u < UF; ++u) {
         if (rl + u * m.rpb >= nrow) break;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float f = xv[u].get(j);
-          v[0][j] += f;
-          v[1][j] += f * f;
-        }
+        t.add(xv[u]);
       }
     }
   }
-  block_reduce_to_replica<2>(v, m, C, sh, sums, repl);
+  block_stats_to_replica(t, m, C, shd, sums, repl);
 }
 
 // ---- y = prelu(bn(x)) + residual.  Every block folds the replicated statistics into
@@ -173,7 +236,7 @@ struct BnApplyArgs {
   u16* y;
   int64_t M;
   int C, HW, RB;
-  const float* sums;      // [REPL][2][C] statistics of x
+  const double* sums;     // [REPL][2][C] statistics of x (float64 sums)
   const float* gamma;
   const float* beta;
   const float* slope;     // PReLU or nullptr
@@ -183,7 +246,7 @@ struct BnApplyArgs {
   float* running_mean;    // or nullptr
   float* running_var;
   float eps, momentum;
-  float* out_sums;        // [REPL][2][C] statistics of y (pre-zeroed) or nullptr
+  double* out_sums;       // [REPL][2][C] statistics of y (float64, pre-zeroed) or nullptr
   int out_nchw;           // 1: y index = n*(C*HW) + c*HW + hw (the flatten order of the reference's fc input)
   int xcd;                // 1: block -> row range in XCD-major order (bn_block_id)
   int repl;               // replicas in use (vlsfr::g_bn_repl)
@@ -194,21 +257,22 @@ struct BnApplyArgs {
 template <int FLAGS>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
   constexpr bool PRELU = FLAGS & 1, RESID = FLAGS & 2, OSUMS = FLAGS & 4, NCHW = FLAGS & 8, RELU_AFTER = FLAGS & 16;
-  extern __shared__ float sh[];   // scale[C], shift[C]; reused by the output-statistics reduction
+  extern __shared__ __attribute__((aligned(8))) float sh[];   // scale[C], shift[C]; reused (as 2 C doubles) by the output-statistics reduction
   const int C = a.C;
   const int tid = threadIdx.x;
-  const float invM = 1.f / (float)a.M;
   for (int c = tid; c < C; c += 256) {
-    float s = 0.f, q = 0.f;
+    double sd = 0.0, qd = 0.0;
 #pragma unroll 8
     for (int r = 0; r < a.repl; ++r) {
-      s += a.sums[(size_t)r * 2 * C + c];
-      q += a.sums[(size_t)r * 2 * C + C + c];
+      sd += a.sums[(size_t)r * 2 * C + c];
+      qd += a.sums[(size_t)r * 2 * C + C + c];
     }
-    const float mean = s * invM;
-    float var = q * invM - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    const float invstd = rsqrtf(var + a.eps);
+    const double mean_d = sd / (double)a.M;
+    double var_d = qd / (double)a.M - mean_d * mean_d;       // float64 sums: the cancellation costs 1e-16 * mean^2, not 1e-7
+    var_d = var_d > 0.0 ? var_d : 0.0;
+    const float mean = (float)mean_d;
+    const float var = (float)var_d;
+    const float invstd = (float)(1.0 / sqrt(var_d + (double)a.eps));
     const float g = a.gamma ? a.gamma[c] : 1.f;
     const float b = a.beta ? a.beta[c] : 0.f;
     sh[c] = g * invstd;
@@ -225,13 +289,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
   }
   __syncthreads();
   const RowMap m = row_map(C);
-  float sc[8], sf[8], sl[8], v[2][8];
+  float sc[8], sf[8], sl[8];
+  StatAcc osum;
+  osum.init();
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = m.col * 8 + j;
     sc[j] = sh[c];
     sf[j] = sh[C + c];
-    v[0][j] = v[1][j] = 0.f;
   }
   load8(PRELU ? a.slope : nullptr, m.col * 8, 1.f, sl);
   __syncthreads();   // sh is reused below
@@ -276,17 +341,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs a) {
         if (OSUMS) {
           bf8 yv;
           yv.raw = packed;   // statistics of what the next layer will actually read
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float f = yv.get(j);
-            v[0][j] += f;
-            v[1][j] += f * f;
-          }
+          osum.add(yv);
         }
       }
     }
   }
-  if (OSUMS) block_reduce_to_replica<2>(v, m, C, sh, a.out_sums, a.repl);
+  if (OSUMS) {
+    __syncthreads();   // (threads without rows skipped the loop: everybody is past the last use of sh as scale / shift)
+    block_stats_to_replica(osum, m, C, (double*)sh, a.out_sums, a.repl);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -782,21 +845,21 @@ static int bn_geom(int64_t M, int C, int* RB, int* nblk) {
   return 0;
 }
 
-int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, float* sums, void* stream) {
+int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, double* sums, void* stream) {
   if (!x || !sums || M <= 0 || C <= 0 || C % 8 || C > 2048)
     return fail(VLSFR_EINVAL, "vlsfr_bn_stats: need C %% 8 == 0, C <= 2048 (got %d)", C);
   int RB, nblk;
   bn_geom(M, C, &RB, &nblk);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(nblk), dim3(256), 2 * C * sizeof(double), (hipStream_t)stream,
                      (const u16*)x, M, C, RB, sums, vlsfr::g_bn_repl);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_stats");
   return VLSFR_OK;
 }
 
-int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const float* sums, const float* gamma,
+int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const double* sums, const float* gamma,
                    const float* beta, const float* slope, const void* residual, float* save_mean,
                    float* save_invstd, float* running_mean, float* running_var, float eps, float momentum,
-                   float* out_sums, int32_t out_nchw, void* stream) {
+                   double* out_sums, int32_t out_nchw, void* stream) {
   if (!x || !y || !sums || !save_mean || !save_invstd || M <= 0 || C <= 0 || C % 8 || C > 2048 || HW <= 0)
     return fail(VLSFR_EINVAL, "vlsfr_bn_apply: bad argument");
   const bool relu_after = (out_nchw & 2) != 0;   // bit 1 of out_nchw: y = relu(bn(x) + residual)
@@ -809,7 +872,7 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
                 save_invstd, running_mean, running_var, eps, momentum, out_sums, out_nchw, g_bn_xcd && nblk >= 16, vlsfr::g_bn_repl};
   const int flags = (slope ? 1 : 0) | (residual ? 2 : 0) | (out_sums ? 4 : 0) | (out_nchw ? 8 : 0) | (relu_after ? 16 : 0);
   const dim3 grid(nblk), block(256);
-  const size_t shb = 2 * C * sizeof(float);
+  const size_t shb = 2 * C * (out_sums ? sizeof(double) : sizeof(float));
   hipStream_t st = (hipStream_t)stream;
 #define VLSFR_CASE(F) case F: hipLaunchKernelGGL(bn_apply_kernel<F>, grid, block, shb, st, a); break;
   switch (flags) {

@@ -137,7 +137,7 @@ int build(vlsfr_resnet* n) {
 
   // ctx: statistics (+ the zero slope vector and the split-K fc accumulator) first, one memset clears them
   n->sums_begin = n->ctx_bytes;
-  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * b.C * 4); };
+  auto sums = [&](Bn& b) { b.off_sums = n->take_ctx((size_t)VLSFR_BN_REPL * 2 * b.C * 8); };
   auto each_bn = [&](auto&& f) {
     f(n->stem_bn);
     for (auto& b : n->blocks) {
@@ -239,7 +239,7 @@ int bn_forward(const vlsfr_resnet* n, const Bn& b, const void* x, void* y, int64
                int out_flags, const float* const* params, float* const* running, char* ctx, void* st) {
   float* rm = running ? running[2 * b.run] : nullptr;
   float* rv = running ? running[2 * b.run + 1] : nullptr;
-  return vlsfr_bn_apply(x, y, M, b.C, HW, (const float*)(ctx + b.off_sums), params[b.p_w], params[b.p_b],
+  return vlsfr_bn_apply(x, y, M, b.C, HW, (const double*)(ctx + b.off_sums), params[b.p_w], params[b.p_b],
                         relu ? (const float*)(ctx + n->off_zero_slope) : nullptr, residual, (float*)(ctx + b.off_mean),
                         (float*)(ctx + b.off_invstd), rm, rv, BN_EPS, BN_MOM, nullptr, out_flags, st);
 }
@@ -309,7 +309,7 @@ int vlsfr_resnet_forward(const vlsfr_resnet* n, const float* x_nchw, const float
   hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_resnet_forward: memset: %s", hipGetErrorString(e));
   const int B = n->B;
-  auto sums_of = [&](const Bn& b) { return (float*)(ctx + b.off_sums); };
+  auto sums_of = [&](const Bn& b) { return (double*)(ctx + b.off_sums); };
   // stem (resnet_std.py:186-189): 7x7/2 conv -> BN -> ReLU -> 3x3/2 max-pool
   RUN(vlsfr_stem7_im2col(x_nchw, ctx + n->off_cols, B, n->S, n->S, st));
   RUN(vlsfr_conv2d_fwd(&n->stem.d, ctx + n->off_cols, wc + n->stem.off_wb, ctx + n->off_c0, 1, 0, sums_of(n->stem_bn), st));

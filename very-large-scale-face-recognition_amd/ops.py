@@ -70,7 +70,7 @@ def conv2d_wgrad(dy, x, desc, dw=None, splitk=0):
 
 
 def new_sums(C, device):
-    return torch.zeros(BN_REPL, 2, C, dtype=torch.float32, device=device)
+    return torch.zeros(BN_REPL, 2, C, dtype=torch.float64, device=device)       # float64 sums (include/vlsfr.h section 6)
 
 
 def bn_stats(x, M, C):
