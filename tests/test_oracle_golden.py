@@ -91,13 +91,13 @@ def test_head_oracle_matches_reference(fname):
         np.testing.assert_array_equal(queue[:, case["touched"]].numpy(), case["queue_touched"])
 
 
-def build_oracle_from_step(z, tag, dtype=torch.float64):
+def build_oracle_from_step(z, tag, dtype=torch.float64, emulate_bf16=False):
     """The oracle set to the golden case's warm state.  float64 by default: the golden step vectors
-    are the reference's float64 arithmetic."""
+    are the reference's float64 arithmetic.  emulate_bf16: round where the device stores bf16 (oracle/backbones_ref.py)."""
     Q, D, B, seed = [int(v) for v in z["meta"]]
     layers = (1, 1, 1, 1) if tag == "irtiny" else None
     net = "irtiny" if tag == "irtiny" else "mobile"
-    o = ffc_ref.FFCRef(net, D, Q, 32.0, "Arc", 0.5, 0.99, layers=layers)
+    o = ffc_ref.FFCRef(net, D, Q, 32.0, "Arc", 0.5, 0.99, layers=layers, emulate_bf16=emulate_bf16)
     sd = common.fill_state({k: v.detach() for k, v in o.probe.items()}, seed)
     cast = lambda v: v.to(dtype) if v.is_floating_point() else v.clone()
     o.probe = {k: cast(v) for k, v in sd.items()}

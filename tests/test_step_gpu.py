@@ -69,19 +69,32 @@ def test_step_matches_reference_golden(tag):
     assert min_cos(embs[0], z["emb_probe_x"]) >= tol["cos"]
     assert min_cos(embs[1], z["emb_probe_y"]) >= tol["cos"]
     np.testing.assert_allclose(float(loss.detach()), float(z["loss"]), rtol=tol["loss"])
-    # gradients
+    # gradients.  The calibrated band (ADVICE r01 / VERDICT r02): what bf16 STORAGE alone does to this step — the float64
+    # oracle with the device's rounding points against the reference's plain float64 vectors.  The device may deviate from the
+    # reference by at most twice that, per tensor (or twice the band over all sampled tensors, where a tensor's own is tiny),
+    # and never by more than the absolute cap in `tol`.
+    from tests.test_oracle_golden import build_oracle_from_step
+    oe, xe, ye, xle, yle = build_oracle_from_step(z, tag, emulate_bf16=True)
+    oe.forward(xe, ye, xle, yle).backward()
+    band = {}
+    for key in z.files:
+        if key.startswith("grad/") and np.abs(z[key]).max() >= 1e-6:
+            band[key] = rel_l2(sample(oe.probe[key[5:]].grad.numpy()), z[key])
+    num = sum(float(((sample(oe.probe[k[5:]].grad.numpy()) - z[k]) ** 2).sum()) for k in band)
+    band_all = float(np.sqrt(num / sum(float((z[k] ** 2).sum()) for k in band)))
     names = [str(n) for n in z["grad_names"]]
     pn = dict(m.probe_net.named_parameters())
     gn = np.asarray([float(pn[n].grad.norm()) for n in names])
     big = z["grad_norms"] > 1e-3 * z["grad_norms"].max()
-    np.testing.assert_allclose(gn[big], z["grad_norms"][big], rtol=tol["gnorm"])
-    for key in z.files:
-        if key.startswith("grad/"):
-            want = z[key]
-            if np.abs(want).max() < 1e-6:
-                continue    # bias in front of a BatchNorm: exactly zero gradient in exact arithmetic
-            got = sample(pn[key[5:]].grad.detach().cpu().numpy())
-            assert rel_l2(got, want) < tol["gl2"], (key, rel_l2(got, want))
+    np.testing.assert_allclose(gn[big], z["grad_norms"][big], rtol=min(tol["gnorm"], 2 * band_all + 2e-2))
+    worst = (None, 0.0, 0.0)
+    for key in band:
+        got = sample(pn[key[5:]].grad.detach().cpu().numpy())
+        err, lim = rel_l2(got, z[key]), min(tol["gl2"], 2.0 * max(band[key], band_all, 1e-2))
+        if err / lim > worst[1] / max(worst[2], 1e-30):
+            worst = (key, err, lim)
+        assert err <= lim, (key, err, band[key], band_all)
+    print("%s: bf16-storage band over the sampled gradients %.3f; tightest tensor %s: device %.3f, bound %.3f" % ((tag, band_all) + worst))
     # optimizer step + EMA
     opt.step()
     torch.cuda.synchronize()

@@ -102,7 +102,7 @@ int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range o
 int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
-int g_tile256 = 2;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
+int g_tile256 = 1;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
 int g_bnred_all = 0;         // "bnred_all": 1 = the fused BatchNorm-backward reduction on every eligible launch (default: where it pays)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
 long long* g_conv_trace = nullptr;   // device buffer [2][64][8] stamps, set by vlsfr_conv_trace
