@@ -63,8 +63,11 @@ def parse():
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
     ap.add_argument("--overlap-wgrad", action="store_true", help="A/B: weight gradients of each backward pass on a side stream "
                     "(vlsfr_iresnet_backward_overlap; measured slower, off by default)")
-    ap.add_argument("--counters-only", action="store_true", help="stop after the timed region (for rocprofv3 --pmc passes: per-launch "
-                    "HIP events from several host threads under counter collection crashed the profiler)")
+    ap.add_argument("--counters-only", action="store_true", help="stop after the timed region: what a rocprofv3 --pmc pass needs.  On by "
+                    "itself under counter collection (ROCPROF_COUNTER_COLLECTION=1): rocprofv3 --pmc over the FULL run (~36 000 "
+                    "dispatches) ends in a SIGSEGV on a non-main thread inside a memcpy of the tool in about one run of three, with "
+                    "the per-launch event brackets taken from a pre-created pool as well as with per-launch hipEventCreate "
+                    "(gpurun_out/pmc_full, prof_r03): a tool-side failure that grows with the dispatch count, so PMC passes stay short")
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') around two steps")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, identity-sharded pool, "
                     "partitioned SGD, every collective) even with one rank: rehearses the RCCL calls on a 1-GPU box")
@@ -350,6 +353,10 @@ def main():
         L.vlsfr_profile_reset()
         return out
 
+    if os.environ.get("ROCPROF_COUNTER_COLLECTION") == "1" and not args.counters_only:
+        note("rocprofv3 counter collection detected (ROCPROF_COUNTERS=%s): stopping after the timed region (--counters-only)" %
+             os.environ.get("ROCPROF_COUNTERS", "?"))
+        args.counters_only = True
     if args.counters_only:   # rocprofv3 --pmc passes: the K timed steps are all that is wanted (no HIP events anywhere)
         if rank == 0:
             emit(json.dumps({"value": round(world * 2 * B * args.steps / dt, 2), "unit": "faces/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),

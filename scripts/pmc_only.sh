@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r02f; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_${1:-r03}; mkdir -p $O; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --counters-only > $O/pmc_fetch.log 2>&1
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --counters-only > $O/pmc_write.log 2>&1

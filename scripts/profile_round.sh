@@ -14,9 +14,9 @@ echo "serial trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kc -o c -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/conc.log 2>&1
 cp $(find /tmp/kc -name "c_kernel_stats.csv" | head -1) $O/bench_concurrent_kernel_stats.csv; grep "^{" $O/conc.log > $O/bench_concurrent_profiled.json
 echo "concurrent trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pf -o f -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --counters-only > $O/pmc_fetch.log 2>&1
 echo "fetch pass done"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial > $O/pmc_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pw -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --serial --counters-only > $O/pmc_write.log 2>&1
 echo "write pass done"
 python3 $R/scripts/pmc_traffic.py $(find /tmp/pf -name 'f_counter_collection.csv' | head -1) $(find /tmp/pw -name 'w_counter_collection.csv' | head -1) $O/pmc_traffic.json ir100 256 10485760
 # config C5's shape with the fp8 class matmul (MobileFaceNet + 10 485 760 identities, batch_size 256): kernel-trace stats
