@@ -361,6 +361,39 @@ def test_conv_batch_256_equals_small_batch_kernel_on_slices(cin, cout, k, stride
     close(dw, dw_sum.float().cpu(), 1e-3)
 
 
+@pytest.mark.parametrize("N,opt", [(230, 1), (256, 1), (230, 0)], ids=["224-ragged", "224-exact", "256-ragged"])
+def test_conv_one_round_tiles_of_the_256_channel_layers(N, opt):
+    """The 256 x 224 (tile224, default) and 256 x 256 8-wave tiles that the 256-channel 14 x 14 layers take when one
+    round of them covers the batch: every 4-image slice equals the 128 x 128-tile kernel's result on that slice bit for
+    bit (same k order), also in the partial last tile (N = 230: 45 080 pixels = 201 tiles of 224 + 56 pixels), and the
+    fused BatchNorm statistics equal the sums of the stored values."""
+    from vlsfr_amd import ops
+    hw, cin, cout, k, n = 14, 256, 256, 3, 4
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16)
+    dy = torch.randn(N, hw, hw, cout, device="cuda", generator=gen).to(torch.bfloat16)
+    w = (torch.randn(cout, k, k, cin, device="cuda", generator=gen) * 0.05).contiguous()
+    wb, wT = ops.cast_weight(w, cout, k * k, cin)
+    big, small = ops.ConvDesc(N, hw, hw, cin, cout, k, k, 1, 1), ops.ConvDesc(n, hw, hw, cin, cout, k, k, 1, 1)
+    import ctypes
+    from vlsfr_amd import _lib
+    set_opt = lambda v: _lib.lib().vlsfr_set_option(b"tile224", ctypes.c_int32(v))
+    set_opt(opt)
+    try:
+        stats = ops.new_sums(cout, "cuda")
+        y = ops.conv2d_fwd(x, wb, big, stats=stats)
+        dx = ops.conv2d_dgrad(dy, wT, big)
+    finally:
+        set_opt(1)
+    for s0 in (0, 56, N - 6, N - 4):     # N - 6: the slice that straddles the last full tile and the partial one
+        assert torch.equal(ops.conv2d_fwd(x[s0:s0 + n].contiguous(), wb, small), y[s0:s0 + n])
+        assert torch.equal(ops.conv2d_dgrad(dy[s0:s0 + n].contiguous(), wT, small), dx[s0:s0 + n])
+    yf = y.double().reshape(-1, cout)
+    st = stats.sum(0).cpu()
+    close(st[0], yf.sum(0).cpu(), 2e-5)           # fp32 partial sums per wave (<= 128 pixels), float64 above
+    close(st[1], (yf * yf).sum(0).cpu(), 2e-5)
+
+
 # ---- operators of the torchvision-style ResNet (reference model/resnet_std.py) ---------------------------------
 def test_stem7_im2col_matches_conv():
     from vlsfr_amd import ops

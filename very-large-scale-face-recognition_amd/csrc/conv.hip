@@ -102,6 +102,7 @@ int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range o
 int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
+int g_tile224 = 1;           // "tile224": 256 x 224 tiles where those still make one round of the 256 CUs (ir100 at batch 256: 224 tiles, not 196)
 int g_tile256 = 1;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
 int g_bnred_all = 0;         // "bnred_all": 1 = the fused BatchNorm-backward reduction on every eligible launch (default: where it pays)
 int g_conv_dbg = 0;          // "conv_dbg": weight-gradient diagnostics (1 skips the epilogue atomics, 2 the k loop)
@@ -389,12 +390,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   // pixel, so v_permlane16_swap hands the even rows both halves of pixel tile j and the odd rows both
   // halves of tile j + 1 -- 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail of a workgroup
   // is issue-bound, not bandwidth-bound).
-  static_assert(NT % 2 == 0, "pixel tiles are stored in pairs");
+  // An odd NT (the 224-pixel tile: 7 pixel tiles per wave) stores its last tile as it stands, 8 bytes per lane.
   const bool odd = h & 1;
   // output row of the pixel tile this lane stores in pair jp (tile 2 jp + odd): the pixel index itself, or — parity-class
   // launch — the position (n, 2 h' + ph, 2 w' + pw) of pixel (n, h', w') of the class grid, advanced 32 pixels per pair
   // by carries (one division pair per lane)
-  int64_t orow[NT / 2];
+  int64_t orow[NT / 2 + 1];
   if (a.cls) {
     const int ph = (a.cls - 1) >> 1, pwc = (a.cls - 1) & 1;
     const int q = pw + (odd ? 16 : 0);
@@ -457,6 +458,25 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   const bool full_tile = p0 + BN <= P && m0 + BM <= a.Mrows;
   if (full_tile) store(std::true_type{});
   else store(std::false_type{});
+  if constexpr (NT % 2 == 1) {   // the unpaired last pixel tile (never a parity-class launch: run_igemm)
+    constexpr int j = NT - 1;
+    const bool pok = full_tile || pw + j * 16 < P;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const bool ok = pok && (full_tile || mw + i * 16 < a.Mrows);
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = (__bf16)acc[i][j][e];
+        if constexpr (!RED) {
+          const float f = ok ? (float)o[e] - cp[i][e] : 0.f;
+          cs[i][e] += f;
+          cq[i][e] += f * f;
+        }
+      }
+      if (ok) *(uint2*)((u16*)a.y + (size_t)(pw + j * 16) * a.Mrows + mw + i * 16) = __builtin_bit_cast(uint2, o);
+    }
+  }
   // Per-channel sums -> one of VLSFR_BN_REPL replicated accumulators out[rep][q][Mrows].  A lane's partial for channel
   // 16 i + 4 h + e (of this wave's channel range) is summed over the 16 pixel lanes of its row with DPP adds (no LDS round
   // trips) and kept by lane r16 = 4 (i & 3) + e; the WN pixel halves of the workgroup meet in the LDS stage the last k-tile
@@ -617,7 +637,12 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   constexpr int CPR = BK / 8;           // 16-byte chunks per row
   constexpr int RPI = 1024 / RSB;       // rows covered by one 1-KiB LDS-DMA wave-instruction
   constexpr int AI = BM / (NW * RPI);   // LDS-DMA instructions per wave and stage, weight tile
-  constexpr int BI = BN / (NW * RPI);   // pixel tile
+  // pixel tile: BROWS instructions; they divide evenly over the waves (wave w issues BI consecutive ones) or — the
+  // 224-pixel tile: 28 instructions on 8 waves — are dealt round-robin (instruction i * NW + w), the last round partial
+  constexpr int BROWS = BN / RPI;
+  constexpr bool BSPLIT = BROWS % NW != 0;
+  constexpr int BI = (BROWS + NW - 1) / NW;
+  static_assert(BM % (NW * RPI) == 0 && BN % RPI == 0 && (!BSPLIT || NST == 2), "tile rows per LDS-DMA instruction");
   constexpr int STAGE = (BM + BN) * RSB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -673,7 +698,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
     // pixel coordinates: one division for the first row of this lane, the other rows (RPI pixels
     // further each) by carry; tap validity as the outer product of 3 row bits and 3 column bits,
     // both in closed form (filters are at most 3 x 3)
-    int p = p0 + wave * BI * RPI + rsub;
+    constexpr int PSTEP = BSPLIT ? NW * RPI : RPI;   // pixels between this lane's rows of instructions i and i + 1
+    int p = p0 + (BSPLIT ? wave : wave * BI) * RPI + rsub;
     const int HoWo = a.Ho * a.Wo;
     const int pc = p < P ? p : (P > 0 ? P - 1 : 0);
     int n = pc / HoWo;
@@ -703,9 +729,9 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
       const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << a.S : 0u) | ((vh & 4u) ? vw << (2 * a.S) : 0u);
       b_mask[i] = p < P ? mask : 0u;
       b_off[i] = ((((n * a.H + bh) * a.W + bw) * a.C) + lchunk * 8) * 2;
-      // advance RPI pixels (one or two row carries on the feature maps, RPI of them on the 1 x 1 "image" of the FC)
-      p += RPI;
-      wo += RPI;
+      // advance PSTEP pixels (a few row carries on the feature maps, PSTEP of them on the 1 x 1 "image" of the FC)
+      p += PSTEP;
+      wo += PSTEP;
       while (wo >= a.Wo) {
         wo -= a.Wo;
         if (++ho >= a.Ho) {
@@ -741,8 +767,10 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
                                                0);
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
+      const int bq = BSPLIT ? i * NW + wave : wave * BI + i;   // instruction of the pixel tile (wave-uniform)
+      if (BSPLIT && bq >= BROWS) continue;
       const int off = (b_mask[i] & bit) ? b_off[i] + toff * 2 : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + BM * RSB + (wave * BI + i) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + BM * RSB + bq * 1024), 16, off, 0, 0, 0);
     }
     if (++is_j >= ntap) {
       is_j = 0;
@@ -1759,7 +1787,10 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
       // (scripts/conv_shapes.py: 73.4 vs 81.7 us; at equal fill the two tiles run at the same rate, 995 vs 954 TFLOP/s).
       // "tile256": 0 off, 1 forward + input gradient (the fused BatchNorm-backward reduction has no 256 x 256 form: that
       // launch then takes the stand-alone reduction kernel), 2 forward only (default)
-      rc = launch_igemm_glds<256, 256, 64, 2, 8>(a, P, st);
+      // 224 pixels per tile where that is still one round: 50 176 pixels = 224 tiles of 224 on 256 CUs instead of 196 of 256,
+      // i.e. 0.875 of the work on the critical CU ("tile224", scripts/conv_shapes.py)
+      if (g_tile224 && (P + 223) / 224 <= 256) rc = launch_igemm_glds<256, 224, 64, 2, 8>(a, P, st);
+      else rc = launch_igemm_glds<256, 256, 64, 2, 8>(a, P, st);
     } else if (red_here) {
       // measured per launch at batch 256 (scripts/dgrad_bnred_micro.py): the fused epilogue beats "plain launch + stand-alone
       // reduction kernel" on the 128 x 128 tiles of the stride-1 layers (128 / 256 / 512 channels: 4 - 9 us saved of 20 - 30)
@@ -1832,6 +1863,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "tile256")) {
     g_tile256 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "tile224")) {
+    g_tile224 = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "bnred_all")) {
