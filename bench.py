@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
+    ap.add_argument("--fwd-chains", type=int, default=2, choices=(2, 4), help="A/B: 2 = pass by pass, probe beside gallery (default); "
+                    "4 = the four backbone passes of a step on four HIP streams (FFC.embed_both; measured slower: 93.5 vs 90.3 ms)")
     ap.add_argument("--overlap-wgrad", action="store_true", help="A/B: weight gradients of each backward pass on a side stream "
                     "(vlsfr_iresnet_backward_overlap; measured slower, off by default)")
     ap.add_argument("--counters-only", action="store_true", help="stop after the timed region: what a rocprofv3 --pmc pass needs.  On by "
@@ -229,6 +231,7 @@ def main():
     model = FFC(args.net, args.feat, Q, 32.0, args.loss, 0.5, 0.99, pool_device=dev,
                 pool_shard=(rank, pool_world) if sharded else None).cuda()
     model.__dict__['head_dtype'] = args.head_dtype
+    model.__dict__['forward_chains'] = args.fwd_chains
     if args.serial:
         model.__dict__['concurrent_streams'] = False
         model.probe_net.concurrent_backward = False

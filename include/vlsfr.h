@@ -530,6 +530,12 @@ int vlsfr_relu_bwd_bf16(const void* dy, const void* y, void* dx, int64_t M, int3
 int vlsfr_sgd_nesterov(const int64_t* table_dev, int32_t n_chunks, float lr, float momentum,
                        float weight_decay, int32_t nesterov, void* stream);
 int vlsfr_ema(const int64_t* table_dev, int32_t n_chunks, float m, void* stream);
+/* The two forward passes of a step (ffc.py:264-267) update every BatchNorm's running statistics one after the other
+ * (torch.nn.BatchNorm2d, momentum 0.1: r <- (1 - m) r + m s).  When the passes run side by side on their own HIP
+ * streams, each is handed a ZEROED table in place of the running buffers, so the unchanged kernels leave d_k = m s_k
+ * there; this call then applies both updates in pass order: r <- (1 - m) ((1 - m) r + d_0) + d_1.
+ * table_dev rows: {running, d_0, d_1, count}. */
+int vlsfr_running_merge(const int64_t* table_dev, int32_t n_chunks, float momentum, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 9. Measurement support: while enabled, every launch of the profiled kernel families is bracketed by HIP

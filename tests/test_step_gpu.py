@@ -125,16 +125,32 @@ def test_streams_do_not_change_the_step(tag):
     gradient tensor (fp32 atomics reorder sums, hence a tolerance instead of bit equality)."""
     z = np.load(os.path.join(G, "step_%s.npz" % tag))
     outs = []
-    for concurrent in (False, False, True):
+    for concurrent, chains in ((False, 2), (False, 2), (True, 2), (True, 4)):
         m, x, y, xl, yl = build_ffc(z, tag)
         m.concurrent_streams = concurrent
+        m.forward_chains = chains
         m.probe_net.concurrent_backward = concurrent
         loss = m(x, y, xl, yl)
         loss.backward()
         torch.cuda.synchronize()
         outs.append((float(loss.detach()), m.queue.clone(), m.lru.state_dict(), m._state().qp.copy(),
-                     {k: p.grad.clone() for k, p in m.probe_net.named_parameters() if p.grad is not None}))
-    (l0, q0, s0, qp0, g0), (l0b, q0b, _, _, g0b), (l1, q1, s1, qp1, g1) = outs
+                     {k: p.grad.clone() for k, p in m.probe_net.named_parameters() if p.grad is not None},
+                     {n + k: b.clone() for n, net in (("p.", m.probe_net), ("g.", m.gallery_net)) for k, b in net.named_buffers()
+                      if k.endswith("running_mean") or k.endswith("running_var")}))
+    # four chains (FFC.embed_both: both passes' backbones side by side, running statistics merged afterwards): the same
+    # bounds as the two-chain schedule, and the running statistics after the two updates of the step
+    (l0, q0, s0, qp0, g0, r0), (l4, q4, s4, qp4, g4, r4) = outs[0], outs[3]
+    assert r0.keys() == r4.keys() and len(r0) >= 20
+    for k in r0:
+        scale = float(r0[k].abs().max()) + 1e-6
+        assert float((r0[k] - r4[k]).abs().max()) <= (2e-2 if tag == "mobile" else 2e-3) * scale, k
+    outs = [o[:5] for o in outs]
+    for (l0, q0, s0, qp0, g0), (l0b, q0b, _, _, g0b), (l1, q1, s1, qp1, g1) in ((outs[0], outs[1], outs[2]), (outs[0], outs[1], outs[3])):
+        _compare_schedules(tag, (l0, q0, s0, qp0, g0), (l0b, q0b, g0b), (l1, q1, s1, qp1, g1))
+
+
+def _compare_schedules(tag, a, b, c):
+    (l0, q0, s0, qp0, g0), (l0b, q0b, g0b), (l1, q1, s1, qp1, g1) = a, b, c
     # Run-to-run noise of the single-stream order itself: the BN statistics are summed with fp32 atomics in
     # arrival order and the train-mode BN stack at batch 8 amplifies that round-off (MobileFaceNet's loss moves
     # by up to 5e-3 between two identical single-stream runs, scripts/noise_test.py).  The stream schedule has to

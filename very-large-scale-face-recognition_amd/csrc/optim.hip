@@ -53,6 +53,18 @@ __global__ __launch_bounds__(256) void ema_kernel(const int64_t* table, float m)
   for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) e[i] = e[i] * m + p[i] * om;
 }
 
+// r <- (1 - m)^2 r + (1 - m) d0 + d1: the two running-statistics updates of a step applied in order, from the
+// contributions d_k = m * (batch statistic of pass k) that the two concurrent forward passes left in their own buffers
+__global__ __launch_bounds__(256) void running_merge_kernel(const int64_t* table, float m) {
+  const int64_t* row = table + (size_t)blockIdx.x * 4;
+  float* r = (float*)row[0];
+  const float* d0 = (const float*)row[1];
+  const float* d1 = (const float*)row[2];
+  const int n = (int)row[3];
+  const float om = 1.f - m;
+  for (int i = threadIdx.x; i < n; i += 256) r[i] = om * (om * r[i] + d0[i]) + d1[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -64,6 +76,14 @@ int vlsfr_sgd_nesterov(const int64_t* table_dev, int32_t n_chunks, float lr, flo
   hipLaunchKernelGGL(sgd_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, lr, momentum,
                      weight_decay, nesterov);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_sgd_nesterov");
+  return VLSFR_OK;
+}
+
+int vlsfr_running_merge(const int64_t* table_dev, int32_t n_chunks, float momentum, void* stream) {
+  if (!table_dev || n_chunks < 0) return fail(VLSFR_EINVAL, "vlsfr_running_merge: bad argument");
+  if (n_chunks == 0) return VLSFR_OK;
+  hipLaunchKernelGGL(running_merge_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table_dev, momentum);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_running_merge");
   return VLSFR_OK;
 }
 

@@ -162,6 +162,47 @@ class FFC(Module):
         g.record_stream(main)
         return p, g
 
+    def embed_both(self, x, y):
+        """The four backbone passes of a step — probe(x), gallery(y) of the rollback pass and probe(y), gallery(x) of the
+        committing pass (ffc.py:264-267 -> :211-217, :156-161) — on four HIP streams.  They depend on nothing but the inputs
+        and the weights (the EMA of ffc.py:139-145 runs once, before either gallery pass, in both orders of execution), so
+        issuing them together changes no result except the ORDER of the two running-statistics updates of every BatchNorm,
+        which is kept by deferring them (NativeBackbone.begin_deferred_running / merge_deferred_running, called by
+        finish_both).  The idea: a chain alternates MFMA-bound convolutions with HBM-bound normalisation kernels and partial
+        last waves, so more chains should keep a convolution resident more of the time.  MEASURED (ir100, 10 M identities,
+        batch 256, same box, alternating): forward phase 50.9 - 51.1 ms with four chains against 48.3 - 48.6 ms with two,
+        93.5 against 90.3 ms per step — four MFMA-bound kernels side by side cost more in the shared L2 than the gaps they
+        fill, the same outcome as the weight gradients on a fourth stream.  Kept as an option
+        (`forward_chains = 4`, bench.py --fwd-chains 4) with its parity test; the default stays two chains per pass.
+        Returns ((p1, g1, ready1), (p2, g2, ready2)): ready_k = the events a consumer stream waits on for pass k."""
+        main = torch.cuda.current_stream()
+        dev = main.device
+        ch = self.__dict__.get('_chains')
+        if ch is None or ch[0].device != dev:
+            ch = self.__dict__['_chains'] = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        B = int(x.shape[0])
+        with torch.no_grad():
+            self._momentum_update_gallery()
+            self.gallery_net.prepare_weights(B, dev)
+        self.probe_net.prepare_weights(B, dev)
+        self.probe_net.begin_deferred_running()
+        self.gallery_net.begin_deferred_running()
+        for s in ch:
+            s.wait_stream(main)
+        p1, e_p1 = self.probe_net.run_chain(x, 0, ch[0])
+        with torch.no_grad():
+            g1, e_g1 = self.gallery_net.run_chain(y, 0, ch[1])
+        p2, e_p2 = self.probe_net.run_chain(y, 1, ch[2])
+        with torch.no_grad():
+            g2, e_g2 = self.gallery_net.run_chain(x, 1, ch[3])
+        return (p1, g1, (e_p1, e_g1)), (p2, g2, (e_p2, e_g2))
+
+    def finish_both(self):
+        """After the consumers of embed_both have been joined into the current stream: both running-statistics updates
+        of every BatchNorm, in pass order."""
+        self.probe_net.merge_deferred_running()          # the current stream already waits for the four passes (run_chain)
+        self.gallery_net.merge_deferred_running()
+
     def forward_impl(self, p_data, g_data, probe_label, gallery_label):          # ffc.py:153-204
         head = self._ensure_head()
         p, g = self.embed_pair(p_data, g_data, update_gallery=False)
@@ -195,6 +236,23 @@ class FFC(Module):
                 marks.append((name, e))
 
         mark("start")
+        if self.__dict__.get('forward_chains', 2) == 4 and hasattr(self.probe_net, 'run_chain'):   # measured slower (below): opt-in
+            (p1, g1, r1), (p2, g2, r2) = self.embed_both(x, y)
+            for e in r1:
+                hs.wait_event(e)
+            with torch.cuda.stream(hs):
+                loss2 = head.run_pass(p1, g1, x_label, y_label, transactional=True)
+                for e in r2:
+                    hs.wait_event(e)
+                loss1 = head.run_pass(p2, g2, y_label, x_label, transactional=False)
+                total = loss1 + loss2
+            for t in (p1, g1, p2, g2):
+                t.record_stream(hs)
+            main.wait_stream(hs)
+            self.finish_both()
+            mark("head 2")
+            total.record_stream(main)
+            return total
         p1, g1 = self.embed_pair(x, y, update_gallery=True)
         mark("backbones of pass 1")
         hs.wait_stream(main)

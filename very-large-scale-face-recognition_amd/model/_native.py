@@ -2,6 +2,7 @@
 a backbone are parameter containers only; forward / backward are single calls into the C++ executor
 (csrc/iresnet.cpp, csrc/mobilenet.cpp), which accumulates gradients straight into the parameters'
 .grad buffers."""
+import contextlib
 import ctypes
 import weakref
 
@@ -32,7 +33,7 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, x, net, *params):
         ctx.slot = net._fwd_slot
         net._fwd_slot ^= 1
-        emb, ws = net._run_forward(x, save=True, owner=ctx, slot=ctx.slot)
+        emb, ws = net._run_forward(x, save=True, owner=ctx, slot=ctx.slot, chain=net._chain)
         ctx.net, ctx.ws, ctx.B = net, ws, x.shape[0]
         return emb
 
@@ -80,7 +81,9 @@ class NativeBackbone(nn.Module):
         self._scratch_alt = None
         self._ctx_pool = [None, None]      # saved-activation buffers of the two passes of a step, reused across steps
         self._ctx_owner = [None, None]     # weakref to the autograd ctx that still needs the buffer
-        self._eval_ctx = None
+        self._eval_ctx = [None, None]      # saved-activation buffers of the no-grad passes (one per concurrent chain)
+        self._chain = None                 # (stream, pass index) while run_chain() is on the stack
+        self._deferred = None              # zeroed stand-ins for the running statistics (begin_deferred_running)
         self._fwd_slot = 0
         self._join_queued = False
         self._bwd_stream = None
@@ -182,7 +185,20 @@ class NativeBackbone(nn.Module):
         self._ctx_owner[slot] = weakref.ref(owner) if owner is not None else None
         return buf
 
-    def _run_forward(self, x, save, owner=None, slot=0):
+    def _scratch_for(self, k, nbytes, device):
+        """Executor scratch of chain k (0: self._scratch, 1: self._scratch_alt, the one the side-stream backward uses)."""
+        if k == 0:
+            if self._scratch is None or self._scratch.numel() < nbytes or self._scratch.device != device:
+                self._scratch = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            return self._scratch
+        if self._scratch_alt is None or self._scratch_alt.numel() < nbytes or self._scratch_alt.device != device:
+            self._scratch_alt = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._scratch_alt
+
+    def _run_forward(self, x, save, owner=None, slot=0, chain=None):
+        """chain = (stream, k): this pass is pass k (0 / 1) of a step whose passes run side by side (FFC.embed_both) — it
+        executes on `stream`, with scratch / no-grad context k of its own, and (training) leaves its running-statistics
+        contribution in the zeroed table k of begin_deferred_running() instead of updating the buffers."""
         if not x.is_cuda:
             raise _lib.VlsfrError("%s.forward needs a device tensor: the backbone has no CPU path" % type(self).__name__)
         L = _lib.lib()
@@ -191,25 +207,90 @@ class NativeBackbone(nn.Module):
         x = x.contiguous().float()
         h, sizes = self._handle(B, x.device)
         params, running = self._tables()
-        self._prepare(h, sizes, params, x.device)
-        if save:
-            ws = self._ctx_buffer(sizes[1], x.device, owner, slot)
-        else:
-            if self._eval_ctx is None or self._eval_ctx.numel() < sizes[1] or self._eval_ctx.device != x.device:
-                self._eval_ctx = torch.empty(sizes[1], dtype=torch.uint8, device=x.device)
-            ws = self._eval_ctx
-        emb = torch.empty(B, self.feat_dim, dtype=torch.float32, device=x.device)
-        fwd = getattr(L, self._cprefix + "_forward")
-        fwd.restype = ctypes.c_int
-        run_tab = _ptr_array(running) if self.training else None
-        _lib.check(fwd(h, ctypes.c_void_p(x.data_ptr()), _ptr_array(params), run_tab,
-                       ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                       ctypes.c_void_p(self._scratch.data_ptr()), ctypes.c_void_p(emb.data_ptr()), _stream()),
-                   self._cprefix + "_forward")
+        k = chain[1] if chain is not None else 0
+        with (torch.cuda.stream(chain[0]) if chain is not None else contextlib.nullcontext()):
+            self._prepare(h, sizes, params, x.device)
+            scratch = self._scratch_for(k, sizes[2], x.device)
+            if save:
+                ws = self._ctx_buffer(sizes[1], x.device, owner, slot)
+            else:
+                ws = self._eval_ctx[k]
+                if ws is None or ws.numel() < sizes[1] or ws.device != x.device:
+                    ws = self._eval_ctx[k] = torch.empty(sizes[1], dtype=torch.uint8, device=x.device)
+            emb = torch.empty(B, self.feat_dim, dtype=torch.float32, device=x.device)
+            fwd = getattr(L, self._cprefix + "_forward")
+            fwd.restype = ctypes.c_int
+            if not self.training:
+                run_tab = None
+            elif chain is not None:
+                if self._deferred is None:
+                    raise _lib.VlsfrError("run_chain in training mode needs begin_deferred_running() first")
+                run_tab = self._deferred["tabs"][k]
+            else:
+                run_tab = _ptr_array(running)
+            _lib.check(fwd(h, ctypes.c_void_p(x.data_ptr()), _ptr_array(params), run_tab,
+                           ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                           ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(emb.data_ptr()), _stream()),
+                       self._cprefix + "_forward")
         if self.training:
             self._nbt_pending += 1          # num_batches_tracked is materialised lazily (flush_counters)
-        self._keep = x
+        self.__dict__.setdefault("_keep", {})[k] = x      # the input outlives the asynchronous pass
         return emb, ws
+
+    # ---- the two passes of a step side by side (FFC.embed_both) -------------------------------------------------
+    def prepare_weights(self, B, device):
+        """bf16 operand copies on the CURRENT stream (before the chains fork from it)."""
+        h, sizes = self._handle(B, device)
+        params, _ = self._tables()
+        self._prepare(h, sizes, params, device)
+
+    def begin_deferred_running(self):
+        """Zeroed stand-ins for (running_mean, running_var) of every BatchNorm, one set per pass: the executors' kernels
+        compute (1 - m) * 0 + m * s into them, merge_deferred_running() applies both updates in pass order
+        (vlsfr_running_merge).  Called on the stream the chains fork from."""
+        _, running = self._tables()
+        if not running or not self.training:
+            self._deferred = None
+            return
+        key = tuple(b.data_ptr() for b in running)
+        d = self._deferred
+        if d is None or d["key"] != key:
+            pad4 = lambda n: (n + 3) & ~3
+            total = sum(pad4(b.numel()) for b in running)
+            flat = torch.zeros(2, total, dtype=torch.float32, device=running[0].device)
+            views, off = ([], []), 0
+            for b in running:
+                for k in range(2):
+                    views[k].append(flat[k, off:off + b.numel()])
+                off += pad4(b.numel())
+            rows = [[b.data_ptr(), v0.data_ptr(), v1.data_ptr(), b.numel()] for b, v0, v1 in zip(running, views[0], views[1])]
+            import numpy as np
+            tab = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(running[0].device)
+            d = self._deferred = dict(key=key, flat=flat, views=views, tabs=(_ptr_array(views[0]), _ptr_array(views[1])), merge=tab)
+        else:
+            d["flat"].zero_()
+
+    def merge_deferred_running(self, momentum=0.1):
+        d = self._deferred
+        if d is None:
+            return
+        fn = _lib.lib().vlsfr_running_merge
+        fn.restype = ctypes.c_int
+        _lib.check(fn(ctypes.c_void_p(d["merge"].data_ptr()), ctypes.c_int32(d["merge"].shape[0]), ctypes.c_float(momentum),
+                      _stream()), "vlsfr_running_merge")
+
+    def run_chain(self, x, k, stream):
+        """Forward pass k (0 / 1) of the step on `stream` (module call: hooks run).  With autograd the node is created on
+        the CALLER's stream (its backward is scheduled exactly like that of a plain forward).  Returns (output, event): the
+        event marks the output on `stream`; the caller's stream is also made to wait for it, so code that uses the output
+        there (forward hooks, a plain consumer) is ordered after the pass — a consumer that wants to start earlier waits on
+        the event from a stream of its own."""
+        self._chain = (stream, k)
+        try:
+            out = self(x)
+        finally:
+            self._chain = None
+        return out, self.__dict__.pop("_chain_event")
 
     def _ensure_grads(self):
         """.grad buffers in the executor's layout (allocated + zeroed on the CURRENT stream when missing)."""
@@ -310,8 +391,13 @@ class NativeBackbone(nn.Module):
         # the running-statistics update.
         params = self._plist
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _BackboneFn.apply(x, self, *params)
-        return self._run_forward(x, save=False)[0]
+            out = _BackboneFn.apply(x, self, *params)
+        else:
+            out = self._run_forward(x, save=False, chain=self._chain)[0]
+        if self._chain is not None:      # run_chain: order the caller's stream (and with it forward hooks) after the pass
+            ev = self.__dict__["_chain_event"] = self._chain[0].record_event()
+            torch.cuda.current_stream().wait_event(ev)
+        return out
 
     def __del__(self):
         try:
