@@ -39,9 +39,9 @@ IR_SHAPES = [
 
 CONV_VARIANTS = [("conv_glds", 0, "regstage"), ("conv_glds", 1, "glds64x4"), ("conv_glds", 2, "glds32x4"),
                  ("conv_glds", 3, "glds64x2"), ("conv_glds", 4, "glds32x5"), ("conv_glds", 5, "glds8w"),
-                 ("conv_glds", 8, "tile256x128"), ("conv_glds", 9, "pingpong"), ("conv_glds", 14, "swp"), ("conv_glds", 10, "tile256"), ("conv_halo", 2, "halo"),
+                 ("conv_glds", 8, "tile256x128"), ("conv_glds", 9, "pingpong"), ("conv_glds", 14, "swp"), ("conv_glds", 10, "tile256"), ("conv_halo", 2, "halo"), ("conv_halo", 0, "nohalo"),
                  ("wgrad_glds", 0, "wgrad_regstage")]
-CONV_DEFAULTS = {"conv_glds": -1, "conv_halo": 0, "wgrad_glds": 1}
+CONV_DEFAULTS = {"conv_glds": -1, "conv_halo": 1, "wgrad_glds": 1}
 
 
 @pytest.fixture(params=CONV_VARIANTS, ids=[v[2] for v in CONV_VARIANTS])

@@ -90,7 +90,8 @@ namespace {
 int g_use_glds = VLSFR_DEFAULT_CONV_VARIANT;   // "conv_glds": 0 register-staged kernel; LDS-DMA ring: 1 = BK64 x 4 stages, 2 = BK32 x 4,
                                                // 3 = BK64 x 2 (default), 4 = BK32 x 5, 5 = 8-wave tiles, 6 / 7 = BK32 x 3 / x 2, 8 = 256x128 4-wave,
                                                // 9 = ping-pong 8-wave tiles, 10 / 11 = 256x256 / 256x128 8-wave tiles in the standard loop
-int g_use_halo = 0;          // "conv_halo": halo-patch kernel for 3x3 / stride-1 layers: 0 never (no end-to-end gain measured), 1 the 64-channel layers, 2 all
+int g_use_halo = 1;          // "conv_halo": halo-patch kernel for 3x3 / stride-1 layers: 0 never, 1 the 64-channel layers (default: 64 -> 64 at 56 x 56
+                             // 111.8 -> 95.1 us forward, 102.6 -> 88.1 us input gradient; serial step 108.4 -> 107.8 ms), 2 all (slower from 128 channels on)
 int g_wgrad_glds = 1;        // "wgrad_glds": 1 LDS-DMA ring (conv_wgrad_glds_kernel), 0 register-staged kernel
 int g_wgrad_kt = 32;         // "wgrad_kt": pixels per k-tile of the register-staged weight-gradient kernel (32 or 64)
 int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace slabs + ordered reduction (bit-reproducible weight gradients),
