@@ -513,10 +513,31 @@ def test_dgrad_epilogue_accumulates_the_batchnorm_backward_reduction(cin, cout, 
     torch.manual_seed(cin + cout + hw)
     request.addfinalizer(lambda: _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(0)))
     _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(1))       # the fused epilogue wherever it exists, not only where it pays
-    d = ops.ConvDesc(N, hw, hw, cin, cout, 3, 3, stride, 1)
-    Ho = ops.out_hw(hw, 3, stride, 1)
-    w = torch.randn(cout, 3, 3, cin, device="cuda") / np.sqrt(9 * cin)
-    _, wT = ops.cast_weight(w, cout, 9, cin)
+    _check_bnred(cin, cout, 3, stride, hw, N, prelu)
+
+
+# MobileFaceNet's project convolutions (mobilefacenet_def.py:44-45): 1 x 1, so the input gradient contracts over 64 / 128
+# output channels only — ONE or two k-tiles, the x tile of the reduction is fetched under the first and last one
+@pytest.mark.parametrize("cin,cout,hw,N,prelu", [(128, 64, 28, 6, True), (256, 128, 14, 9, True), (512, 128, 7, 11, False)])
+def test_dgrad_bnred_pointwise(cin, cout, hw, N, prelu, request):
+    import ctypes
+    from vlsfr_amd import _lib
+    torch.manual_seed(cin + cout + hw)
+    for force in (1, 0):       # forced everywhere, and as the executor runs it (wide tiles only, else the stand-alone kernel)
+        _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(force))
+        try:
+            _check_bnred(cin, cout, 1, 1, hw, N, prelu)
+        finally:
+            _lib.lib().vlsfr_set_option(b"bnred_all", ctypes.c_int32(0))
+
+
+def _check_bnred(cin, cout, k, stride, hw, N, prelu):
+    from vlsfr_amd import ops
+    pad = k // 2
+    d = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad)
+    Ho = ops.out_hw(hw, k, stride, pad)
+    w = torch.randn(cout, k, k, cin, device="cuda") / np.sqrt(k * k * cin)
+    _, wT = ops.cast_weight(w, cout, k * k, cin)
     dy = (torch.randn(N, Ho, Ho, cout, device="cuda") * 0.05).to(torch.bfloat16)
     x = (torch.randn(N, hw, hw, cin, device="cuda") * (0.5 + torch.rand(cin, device="cuda")) + torch.randn(cin, device="cuda")).to(torch.bfloat16)
     M = N * hw * hw
