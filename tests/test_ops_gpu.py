@@ -361,8 +361,9 @@ def test_conv_batch_256_equals_small_batch_kernel_on_slices(cin, cout, k, stride
     close(dw, dw_sum.float().cpu(), 1e-3)
 
 
-@pytest.mark.parametrize("N,opt", [(230, 1), (256, 1), (230, 0)], ids=["224-ragged", "224-exact", "256-ragged"])
-def test_conv_one_round_tiles_of_the_256_channel_layers(N, opt):
+@pytest.mark.parametrize("N,opt,p8", [(230, 1, 0), (256, 1, 0), (230, 0, 0), (256, 1, 1), (232, 1, 1), (256, 0, 1)],
+                         ids=["224-ragged", "224-exact", "256-ragged", "224-4phase", "224-4phase-203-tiles", "256-4phase"])
+def test_conv_one_round_tiles_of_the_256_channel_layers(N, opt, p8):
     """The 256 x 224 (tile224, default) and 256 x 256 8-wave tiles that the 256-channel 14 x 14 layers take when one
     round of them covers the batch: every 4-image slice equals the 128 x 128-tile kernel's result on that slice bit for
     bit (same k order), also in the partial last tile (N = 230: 45 080 pixels = 201 tiles of 224 + 56 pixels), and the
@@ -378,13 +379,20 @@ def test_conv_one_round_tiles_of_the_256_channel_layers(N, opt):
     import ctypes
     from vlsfr_amd import _lib
     set_opt = lambda v: _lib.lib().vlsfr_set_option(b"tile224", ctypes.c_int32(v))
+    set_p8 = lambda v: _lib.lib().vlsfr_set_option(b"conv_p8", ctypes.c_int32(v))
+    p8_default = 0
     set_opt(opt)
+    set_p8(p8)          # the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the same tiles
     try:
         stats = ops.new_sums(cout, "cuda")
         y = ops.conv2d_fwd(x, wb, big, stats=stats)
         dx = ops.conv2d_dgrad(dy, wT, big)
+        if p8:          # the schedule's LDS hand-offs are timing-dependent if wrong: the same launch, repeatedly
+            for _ in range(10):
+                assert torch.equal(ops.conv2d_fwd(x, wb, big), y) and torch.equal(ops.conv2d_dgrad(dy, wT, big), dx)
     finally:
         set_opt(1)
+        set_p8(p8_default)
     for s0 in (0, 56, N - 6, N - 4):     # N - 6: the slice that straddles the last full tile and the partial one
         assert torch.equal(ops.conv2d_fwd(x[s0:s0 + n].contiguous(), wb, small), y[s0:s0 + n])
         assert torch.equal(ops.conv2d_dgrad(dy[s0:s0 + n].contiguous(), wT, small), dx[s0:s0 + n])

@@ -103,6 +103,7 @@ int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range o
 int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
+int g_conv_p8 = 0;           // "conv_p8": the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the full 256-channel one-round tiles
 int g_tile224 = 1;           // "tile224": 256 x 224 tiles where those still make one round of the 256 CUs (ir100 at batch 256: 224 tiles, not 196)
 int g_tile256 = 1;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
 int g_bnred_all = 0;         // "bnred_all": 1 = the fused BatchNorm-backward reduction on every eligible launch (default: where it pays)
@@ -1012,6 +1013,235 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_p8_kernel -- the 256 x 256 / 256 x 224 tile with a FOUR-PHASE-PER-K-TILE schedule (the "8-phase" GEMM structure
+// of the CDNA4 playbook, two k-tiles per 8 phases): the loop of conv_igemm_glds_kernel issues every fragment read of a k-tile,
+// waits, multiplies, and meets one barrier per tile with the next tile's DMA drained (vmcnt 0) — LDS pipe and matrix pipe take
+// turns.  Here a k-tile is cut into four phases of 16 MFMAs per wave (one quadrant of the wave's 64 x 128 output x K = 64):
+//   phase:   { ds_read of the quadrant's new operand sub-block ; stage ONE half-tile of a later k-tile (2 LDS-DMA instructions) }
+//            s_barrier ; lgkmcnt(0) ; setprio(1) 16 x MFMA setprio(0) ; s_barrier
+// and the two groups of four waves (one wave per SIMD each) run ONE BARRIER APART, so on every SIMD one wave multiplies while the
+// other reads LDS and issues DMA.  The DMA is never drained inside the loop: one counted vmcnt(4) per k-tile leaves the two
+// half-tiles staged last in flight across the barriers.
+//   LDS: two k-tile buffers of [A half 0 | A half 1 | B half 0 | B half 1], 128-byte rows, chunks XOR-swizzled with (row & 7).
+//   The halves are laid out by PHASE OF FIRST USE, not by tile row: A half 0 holds MFMA row tiles i = 0, 1 of every wave
+//   (read in phase 1), half 1 tiles i = 2, 3 (phase 2); B half 0 holds pixel tiles j = 0..3 of every wave (phase 1), half 1
+//   tiles j = 4.. (phase 3) — so a half is dead for ALL waves two phases after its read and can be restaged then:
+//     tile u:  A0 staged in phase 3 of tile u - 2, B0 in phase 4 of u - 2, A1 in phase 1 of u - 1, B1 in phase 2 of u - 1;
+//     phase 4 of tile u - 1 waits vmcnt(4): everything but A0 / B0 of tile u + 1 has landed, i.e. all of tile u, one phase (two
+//     barriers) before its first read.
+//   Quadrants: phase 1 acc[0..1][0..3] (A0 B0), 2 acc[2..3][0..3] (A1 B0), 3 acc[2..3][4..] (A1 B1), 4 acc[0..1][4..] (A0 B1):
+//   every accumulator sees k in the order of the default kernel (bit-identical results).
+// Full tiles only (Mrows % 256 == 0, P % BN == 0), every tap, no split-K: run_igemm falls back to the other kernels otherwise.
+// ------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BK = 64, NW = 8, WM = 4, WN = 2;
+  constexpr int MT = 4, NT = BN / WN / 16, NT0 = 4, NT1 = NT - NT0;
+  constexpr int RSB = 128;
+  constexpr int BH0 = WN * NT0 * 16, BH1 = WN * NT1 * 16;   // rows of the two B halves
+  constexpr int BI1 = BH1 / 8;                              // LDS-DMA instructions of B half 1 (16 or 12)
+  constexpr int STAGE = (BM + BN) * RSB;
+  constexpr int OOB = (int)0x80000000;
+  static_assert(BH0 == 128 && BH0 + BH1 == BN && NT1 >= 1 && NT1 <= 4, "pixel halves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+  const int P = a.Nimg * a.Ho * a.Wo;
+  const int K = a.R * a.S * a.C;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd) {
+    const int g = xcd_major_id(blockIdx.x, a.gx * a.gy);
+    bx = g / a.gy;
+    by = g - bx * a.gy;
+  }
+  const int m0 = by * BM, p0 = bx * BN;
+  const int ntap = a.R * a.S;
+  const int nk = ntap * (a.C / BK);
+
+  // ---- per-lane gather descriptors: instruction i (0..3) of this wave covers LDS rows 8 (8 (i & 1) + wave) .. + 7 of half i >> 1
+  const int rsub = lane >> 3;
+  const int lchunk = (lane & 7) ^ rsub;
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Mrows * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.Nimg * a.H * a.W * a.C * 2), 0x00020000);
+  int a_off[4], b_off[4];
+  uint32_t b_mask[4];
+  {
+    const int HoWo = a.Ho * a.Wo;
+    const uint32_t rbits = (1u << a.R) - 1u, sbits = (1u << a.S) - 1u;
+    const bool fwd = a.mode == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hh = i >> 1;
+      const int rem = ((i & 1) * 8 + wave) * 8 + rsub;          // row inside the half
+      // A: half hh holds, for wave row wm', its MFMA row tiles 2 hh, 2 hh + 1
+      const int m = m0 + (rem >> 5) * 64 + ((hh << 1) | ((rem >> 4) & 1)) * 16 + (rem & 15);
+      a_off[i] = m < a.Mrows ? (m * K + lchunk * 8) * 2 : OOB;
+      // B: half hh holds, for wave column wn', its pixel tiles hh * NT0 + 0 .. NTh - 1
+      const int nth16 = (hh ? NT1 : NT0) * 16;
+      const bool live = hh == 0 || rem < BH1;
+      const int wnp = rem / nth16, rr = rem - wnp * nth16;
+      const int p = p0 + wnp * (BN / WN) + hh * NT0 * 16 + rr;
+      const int pc = (live && p < P) ? p : 0;
+      const int n = pc / HoWo;
+      const int r2 = pc - n * HoWo;
+      const int ho = r2 / a.Wo, wo = r2 - ho * a.Wo;
+      const int bh = fwd ? ho * a.stride - a.pad : ho + a.pad;
+      const int bw = fwd ? wo * a.stride - a.pad : wo + a.pad;
+      uint32_t vh = 0, vw = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int dh = fwd ? r : -r;
+        vh |= ((unsigned)(bh + dh) < (unsigned)a.H) ? (1u << r) : 0u;
+        vw |= ((unsigned)(bw + dh) < (unsigned)a.W) ? (1u << r) : 0u;
+      }
+      vh &= rbits;
+      vw &= sbits;
+      const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << a.S : 0u) | ((vh & 4u) ? vw << (2 * a.S) : 0u);
+      b_mask[i] = (live && p < P) ? mask : 0u;
+      b_off[i] = ((((n * a.H + bh) * a.W + bw) * a.C) + lchunk * 8) * 2;
+    }
+  }
+
+  // k-tile cursors (channel chunk outer, tap inner, as in conv_igemm_glds_kernel): c1 = tile t + 1, c2 = tile t + 2
+  int c1_j = 0, c1_c = 0, c2_j = 0, c2_c = 0;
+  auto adv = [&](int& j, int& c) {
+    if (++j >= ntap) {
+      j = 0;
+      c += BK;
+    }
+  };
+  auto stage_a = [&](int hh, int j, int c, int buf) {
+    const int k0 = j * a.C + c;
+    char* st = smem + buf * STAGE + hh * (128 * RSB);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(st + (e * 8 + wave) * 1024), 16, a_off[2 * hh + e], k0 * 2, 0, 0);
+  };
+  auto stage_b = [&](int hh, int j, int c, int buf) {
+    const int r = j / a.S, sx = j - r * a.S;
+    const int toff = (a.mode == 0 ? (r * a.W + sx) : -(r * a.W + sx)) * a.C + c;
+    const uint32_t bit = 1u << j;
+    char* st = smem + buf * STAGE + BM * RSB + hh * (BH0 * RSB);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (hh == 1 && e * 8 + wave >= BI1) continue;      // the short half (224-pixel tile): wave-uniform
+      const int off = (b_mask[2 * hh + e] & bit) ? b_off[2 * hh + e] + toff * 2 : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(st + (e * 8 + wave) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read bases: byte offset of chunk (4 kk + h) ^ (row & 7) of this lane's row, k-steps 0 and 1
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const uint32_t xk0 = (uint32_t)((h ^ (r16 & 7)) << 4), xk1 = (uint32_t)(((4 + h) ^ (r16 & 7)) << 4);
+  const uint32_t rowA = lds0 + (uint32_t)((wm * 32 + r16) * RSB);
+  const uint32_t rowB0 = lds0 + (uint32_t)(BM * RSB + (wn * NT0 * 16 + r16) * RSB);
+  const uint32_t rowB1 = lds0 + (uint32_t)(BM * RSB + (BH0 + wn * NT1 * 16 + r16) * RSB);
+
+  // ---- prologue: tile 0 complete, A0 / B0 of tile 1 in flight
+  stage_a(0, 0, 0, 0);
+  stage_b(0, 0, 0, 0);
+  stage_a(1, 0, 0, 0);
+  stage_b(1, 0, 0, 0);
+  adv(c1_j, c1_c);
+  c2_j = c1_j;
+  c2_c = c1_c;
+  adv(c2_j, c2_c);
+  if (nk > 1) {
+    stage_a(0, c1_j, c1_c, 1);
+    stage_b(0, c1_j, c1_c, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier behind the first
+
+  bf16x8 fa[2][4], fb[2][4];   // [k-step][tile]: A sub-blocks 0 (tiles 0, 1) and 1 (tiles 2, 3); the current B sub-block
+  auto quad = [&](auto i0_tag, auto j0_tag, auto nj_tag) {
+    constexpr int I0 = decltype(i0_tag)::value, J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[I0 + i][J0 + j] = mfma16(fa[kk][I0 + i], fb[kk][j], acc[I0 + i][J0 + j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  using I_ = std::integral_constant<int, 0>;
+  for (int t = 0; t < nk; ++t) {
+    const int buf = t & 1;
+    const uint32_t sb = (uint32_t)(buf * STAGE);
+    const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+    // ---- phase 1: A sub-block 0, B sub-block 0
+    const uint32_t rA0 = rowA + sb + xk0, rA1 = rowA + sb + xk1;
+    fa[0][0] = lds_read128_asm<0>(rA0);
+    fa[0][1] = lds_read128_asm<16 * RSB>(rA0);
+    fa[1][0] = lds_read128_asm<0>(rA1);
+    fa[1][1] = lds_read128_asm<16 * RSB>(rA1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t b = rowB0 + sb + (kk ? xk1 : xk0);
+      fb[kk][0] = lds_read128_asm<0>(b);
+      fb[kk][1] = lds_read128_asm<16 * RSB>(b);
+      fb[kk][2] = lds_read128_asm<32 * RSB>(b);
+      fb[kk][3] = lds_read128_asm<48 * RSB>(b);
+    }
+    if (more1) stage_a(1, c1_j, c1_c, buf ^ 1);
+    quad(I_{}, I_{}, std::integral_constant<int, NT0>{});
+    // ---- phase 2: A sub-block 1
+    fa[0][2] = lds_read128_asm<128 * RSB>(rA0);
+    fa[0][3] = lds_read128_asm<128 * RSB + 16 * RSB>(rA0);
+    fa[1][2] = lds_read128_asm<128 * RSB>(rA1);
+    fa[1][3] = lds_read128_asm<128 * RSB + 16 * RSB>(rA1);
+    if (more1) stage_b(1, c1_j, c1_c, buf ^ 1);
+    quad(std::integral_constant<int, 2>{}, I_{}, std::integral_constant<int, NT0>{});
+    // ---- phase 3: B sub-block 1 (over sub-block 0's registers)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const uint32_t b = rowB1 + sb + (kk ? xk1 : xk0);
+      fb[kk][0] = lds_read128_asm<0>(b);
+      if constexpr (NT1 > 1) fb[kk][1] = lds_read128_asm<16 * RSB>(b);
+      if constexpr (NT1 > 2) fb[kk][2] = lds_read128_asm<32 * RSB>(b);
+      if constexpr (NT1 > 3) fb[kk][3] = lds_read128_asm<48 * RSB>(b);
+    }
+    if (more2) stage_a(0, c2_j, c2_c, buf);
+    quad(std::integral_constant<int, 2>{}, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT1>{});
+    // ---- phase 4: no new operand; the k-tile's one counted wait
+    if (more2) {
+      stage_b(0, c2_j, c2_c, buf);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    quad(I_{}, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT1>{});
+    c1_j = c2_j;
+    c1_c = c2_c;
+    adv(c2_j, c2_c);
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // both groups past their last LDS read: the epilogue reuses the ring
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, false>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_igemm_halo_kernel -- 3x3 / stride 1 / pad 1 convolutions (forward and input gradient) with the
 // gathered operand kept as ONE halo'd pixel patch per 64-channel chunk instead of nine shifted copies.
 // Written to test whether the per-CU L2->LDS volume (32 KB per 128x128x64 k-tile) bounds the LDS-DMA kernel
@@ -1687,6 +1917,22 @@ int launch_igemm_glds(const ConvArgs& a, int P, hipStream_t st) {
   return VLSFR_OK;
 }
 
+template <int BN>
+int launch_igemm_p8(const ConvArgs& a, int P, hipStream_t st) {
+  constexpr int lds = 2 * (256 + BN) * 128;
+  auto kern = conv_igemm_p8_kernel<BN>;
+  if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_p8")) return rc;
+  dim3 grid(P / BN, a.Mrows / 256, 1);
+  ConvArgs b = a;
+  const size_t nwg = (size_t)grid.x * grid.y;
+  b.gx = (int)grid.x;
+  b.gy = (int)grid.y;
+  b.xcd = g_xcd_map && nwg >= 16 && nwg < (1u << 30);
+  if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, b);
+  return VLSFR_OK;
+}
+
 template <int BM, int PI>
 int launch_igemm_halo(const ConvArgs& a, int P, hipStream_t st) {
   const int PR = ((128 + 2 * a.W + 2) + 7) & ~7;
@@ -1790,7 +2036,11 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
       // launch then takes the stand-alone reduction kernel), 2 forward only (default)
       // 224 pixels per tile where that is still one round: 50 176 pixels = 224 tiles of 224 on 256 CUs instead of 196 of 256,
       // i.e. 0.875 of the work on the critical CU ("tile224", scripts/conv_shapes.py)
-      if (g_tile224 && (P + 223) / 224 <= 256) rc = launch_igemm_glds<256, 224, 64, 2, 8>(a, P, st);
+      const bool p8_ok = g_conv_p8 && a.R * a.S <= 9 && (a.mode == 0 || a.stride == 1) && !a.out_f32 && !a.red_x;
+      if (g_tile224 && (P + 223) / 224 <= 256) {
+        if (p8_ok && P % 224 == 0) rc = launch_igemm_p8<224>(a, P, st);
+        else rc = launch_igemm_glds<256, 224, 64, 2, 8>(a, P, st);
+      } else if (p8_ok && P % 256 == 0) rc = launch_igemm_p8<256>(a, P, st);
       else rc = launch_igemm_glds<256, 256, 64, 2, 8>(a, P, st);
     } else if (red_here) {
       // measured per launch at batch 256 (scripts/dgrad_bnred_micro.py): the fused epilogue beats "plain launch + stand-alone
@@ -1864,6 +2114,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "tile256")) {
     g_tile256 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_p8")) {
+    g_conv_p8 = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "tile224")) {
