@@ -380,7 +380,7 @@ def test_conv_one_round_tiles_of_the_256_channel_layers(N, opt, p8):
     from vlsfr_amd import _lib
     set_opt = lambda v: _lib.lib().vlsfr_set_option(b"tile224", ctypes.c_int32(v))
     set_p8 = lambda v: _lib.lib().vlsfr_set_option(b"conv_p8", ctypes.c_int32(v))
-    p8_default = 0
+    p8_default = 1
     set_opt(opt)
     set_p8(p8)          # the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the same tiles
     try:

@@ -103,7 +103,7 @@ int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range o
 int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
-int g_conv_p8 = 0;           // "conv_p8": the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the full 256-channel one-round tiles
+int g_conv_p8 = 1;           // "conv_p8": the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the full 256-channel one-round tiles
 int g_tile224 = 1;           // "tile224": 256 x 224 tiles where those still make one round of the 256 CUs (ir100 at batch 256: 224 tiles, not 196)
 int g_tile256 = 1;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
 int g_bnred_all = 0;         // "bnred_all": 1 = the fused BatchNorm-backward reduction on every eligible launch (default: where it pays)
@@ -972,6 +972,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
     else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!(a.dbg & 128)) __builtin_amdgcn_s_barrier();                        // dbg 128 (with 32): no barrier (diagnostic)
+    // (issued here, ahead of the fragment reads: between the two MFMA blocks — a cheaper issue slot — the DMA has half a
+    // k-tile less to land in and the 128 x 128 layers ran 7 - 10 % slower)
     if (it + NST - 1 < nk && !(a.dbg & 32)) issue((it + NST - 1) % NST);   // dbg 32: no DMA after the prologue (diagnostic)
     if constexpr (RED) {
       if (it == nk - 1 && !(a.dbg & 4)) issue_x();       // the stage of tile nk - 2 is free: the x tile of the epilogue's reduction goes there
@@ -1028,7 +1030,8 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
 //   tiles j = 4.. (phase 3) — so a half is dead for ALL waves two phases after its read and can be restaged then:
 //     tile u:  A0 staged in phase 3 of tile u - 2, B0 in phase 4 of u - 2, A1 in phase 1 of u - 1, B1 in phase 2 of u - 1;
 //     phase 4 of tile u - 1 waits vmcnt(4): everything but A0 / B0 of tile u + 1 has landed, i.e. all of tile u, one phase (two
-//     barriers) before its first read.
+//     barriers) before its first read.  (A counted wait in EVERY phase with the last four half-tiles left in flight — a whole
+//     k-tile of latency for each — measured 76.6 us against 63.6 us for this form on the 256 -> 256 14 x 14 layer.)
 //   Quadrants: phase 1 acc[0..1][0..3] (A0 B0), 2 acc[2..3][0..3] (A1 B0), 3 acc[2..3][4..] (A1 B1), 4 acc[0..1][4..] (A0 B1):
 //   every accumulator sees k in the order of the default kernel (bit-identical results).
 // Full tiles only (Mrows % 256 == 0, P % BN == 0), every tap, no split-K: run_igemm falls back to the other kernels otherwise.
@@ -1204,14 +1207,15 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
       fb[kk][2] = lds_read128_asm<32 * RSB>(b);
       fb[kk][3] = lds_read128_asm<48 * RSB>(b);
     }
-    if (more1) stage_a(1, c1_j, c1_c, buf ^ 1);
+    const bool dma = !(a.dbg & 32);                      // diagnostic: no DMA after the prologue
+    if (more1 && dma) stage_a(1, c1_j, c1_c, buf ^ 1);
     quad(I_{}, I_{}, std::integral_constant<int, NT0>{});
     // ---- phase 2: A sub-block 1
     fa[0][2] = lds_read128_asm<128 * RSB>(rA0);
     fa[0][3] = lds_read128_asm<128 * RSB + 16 * RSB>(rA0);
     fa[1][2] = lds_read128_asm<128 * RSB>(rA1);
     fa[1][3] = lds_read128_asm<128 * RSB + 16 * RSB>(rA1);
-    if (more1) stage_b(1, c1_j, c1_c, buf ^ 1);
+    if (more1 && dma) stage_b(1, c1_j, c1_c, buf ^ 1);
     quad(std::integral_constant<int, 2>{}, I_{}, std::integral_constant<int, NT0>{});
     // ---- phase 3: B sub-block 1 (over sub-block 0's registers)
 #pragma unroll
@@ -1222,12 +1226,12 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
       if constexpr (NT1 > 2) fb[kk][2] = lds_read128_asm<32 * RSB>(b);
       if constexpr (NT1 > 3) fb[kk][3] = lds_read128_asm<48 * RSB>(b);
     }
-    if (more2) stage_a(0, c2_j, c2_c, buf);
+    if (more2 && dma) stage_a(0, c2_j, c2_c, buf);
     quad(std::integral_constant<int, 2>{}, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT1>{});
     // ---- phase 4: no new operand; the k-tile's one counted wait
-    if (more2) {
+    if (more2 && dma) {
       stage_b(0, c2_j, c2_c, buf);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all of tile t + 1 has landed; A0 / B0 of tile t + 2 stay in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1237,6 +1241,10 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
     adv(c2_j, c2_c);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();   // both groups past their last LDS read: the epilogue reuses the ring
+  if (a.dbg & 64) {                             // diagnostic: no epilogue
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0] + acc[3][NT - 1][3] + acc[1][2][1] + acc[2][5][2];
+    return;
+  }
   conv_epilogue<BM, BN, WM, WN, MT, NT, NW, false>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
 #endif
 }
