@@ -2044,7 +2044,7 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
       // launch then takes the stand-alone reduction kernel), 2 forward only (default)
       // 224 pixels per tile where that is still one round: 50 176 pixels = 224 tiles of 224 on 256 CUs instead of 196 of 256,
       // i.e. 0.875 of the work on the critical CU ("tile224", scripts/conv_shapes.py)
-      const bool p8_ok = g_conv_p8 && a.R * a.S <= 9 && (a.mode == 0 || a.stride == 1) && !a.out_f32 && !a.red_x;
+      const bool p8_ok = g_conv_p8 && a.R * a.S <= 9 && (a.mode == 0 || a.stride == 1) && !a.out_f32;   // (a.red_x: the caller runs the stand-alone reduction)
       if (g_tile224 && (P + 223) / 224 <= 256) {
         if (p8_ok && P % 224 == 0) rc = launch_igemm_p8<224>(a, P, st);
         else rc = launch_igemm_glds<256, 224, 64, 2, 8>(a, P, st);
