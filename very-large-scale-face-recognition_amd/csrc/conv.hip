@@ -1074,6 +1074,21 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.Nimg * a.H * a.W * a.C * 2), 0x00020000);
   int a_off[4], b_off[4];
   uint32_t b_mask[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {   // A: half hh = i >> 1 holds, for wave row wm', its MFMA row tiles 2 hh, 2 hh + 1
+    const int hh = i >> 1;
+    const int rem = ((i & 1) * 8 + wave) * 8 + rsub;
+    const int m = m0 + (rem >> 5) * 64 + ((hh << 1) | ((rem >> 4) & 1)) * 16 + (rem & 15);
+    a_off[i] = m < a.Mrows ? (m * K + lchunk * 8) * 2 : OOB;
+  }
+  // the weight halves of tile 0 go out before the pixel coordinates (two divisions per row) are worked out
+  {
+    char* st0 = smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(st0 + (i >> 1) * (128 * RSB) + ((i & 1) * 8 + wave) * 1024), 16,
+                                               a_off[i], 0, 0, 0);
+  }
   {
     const int HoWo = a.Ho * a.Wo;
     const uint32_t rbits = (1u << a.R) - 1u, sbits = (1u << a.S) - 1u;
@@ -1082,9 +1097,6 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int hh = i >> 1;
       const int rem = ((i & 1) * 8 + wave) * 8 + rsub;          // row inside the half
-      // A: half hh holds, for wave row wm', its MFMA row tiles 2 hh, 2 hh + 1
-      const int m = m0 + (rem >> 5) * 64 + ((hh << 1) | ((rem >> 4) & 1)) * 16 + (rem & 15);
-      a_off[i] = m < a.Mrows ? (m * K + lchunk * 8) * 2 : OOB;
       // B: half hh holds, for wave column wn', its pixel tiles hh * NT0 + 0 .. NTh - 1
       const int nth16 = (hh ? NT1 : NT0) * 16;
       const bool live = hh == 0 || rem < BH1;
@@ -1152,10 +1164,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
   const uint32_t rowB0 = lds0 + (uint32_t)(BM * RSB + (wn * NT0 * 16 + r16) * RSB);
   const uint32_t rowB1 = lds0 + (uint32_t)(BM * RSB + (BH0 + wn * NT1 * 16 + r16) * RSB);
 
-  // ---- prologue: tile 0 complete, A0 / B0 of tile 1 in flight
-  stage_a(0, 0, 0, 0);
+  // ---- prologue: tile 0 complete (its A halves were issued above), A0 / B0 of tile 1 in flight
   stage_b(0, 0, 0, 0);
-  stage_a(1, 0, 0, 0);
   stage_b(1, 0, 0, 0);
   adv(c1_j, c1_c);
   c2_j = c1_j;
