@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--loss", default="Arc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="A/B: one HIP stream (no gallery / second-backward side streams)")
+    ap.add_argument("--graphs", action="store_true", help="replay the backbones' forward / backward executor calls from HIP graphs "
+                    "(NativeBackbone.use_graphs): for launch-bound sizes, e.g. --net mobile --feat 128 --identities 1000 --batch 32")
     ap.add_argument("--fwd-chains", type=int, default=2, choices=(2, 4), help="A/B: 2 = pass by pass, probe beside gallery (default); "
                     "4 = the four backbone passes of a step on four HIP streams (FFC.embed_both; measured slower: 93.5 vs 90.3 ms)")
     ap.add_argument("--overlap-wgrad", action="store_true", help="A/B: weight gradients of each backward pass on a side stream "
@@ -232,6 +234,12 @@ def main():
                 pool_shard=(rank, pool_world) if sharded else None).cuda()
     model.__dict__['head_dtype'] = args.head_dtype
     model.__dict__['forward_chains'] = args.fwd_chains
+
+    def set_graphs(on):
+        for net in (model.probe_net, model.gallery_net):
+            if hasattr(net, "use_graphs"):
+                net.use_graphs = bool(on)
+    set_graphs(args.graphs)
     if args.serial:
         model.__dict__['concurrent_streams'] = False
         model.probe_net.concurrent_backward = False
@@ -365,6 +373,7 @@ def main():
             emit(json.dumps({"value": round(world * 2 * B * args.steps / dt, 2), "unit": "faces/sec", "ms_per_step": round(dt / args.steps * 1e3, 3),
                              "note": "--counters-only run: no roofline legs"}))
         return
+    set_graphs(False)      # the per-launch event brackets below need plain launches
     L.vlsfr_profile_event_overhead_us.restype = ctypes.c_double
     ev_us = float(L.vlsfr_profile_event_overhead_us(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     if not args.timed_profile:

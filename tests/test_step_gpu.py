@@ -170,6 +170,50 @@ def _compare_schedules(tag, a, b, c):
     assert g0.keys() == g1.keys()
 
 
+@pytest.mark.parametrize("tag", ["mobile", "irtiny"])
+def test_graph_replay_equals_plain_launches(tag):
+    """NativeBackbone.use_graphs: the forward / backward executor calls of a step replayed from HIP graphs (captured on the
+    third call with the same buffers) against plain launches.  Five steps on the same inputs with a zero learning rate (the
+    weights stay put, so every step computes the same thing and the comparison is not a chaotic training trajectory): the
+    loss of every step, the gradients of the last one and the BatchNorm running statistics agree within the run-to-run
+    noise of the atomically summed statistics; the allocator state is identical."""
+    from vlsfr_amd.optim.fused import FusedSGD
+    z = np.load(os.path.join(G, "step_%s.npz" % tag))
+    traj = []
+    for graphs in (False, True):
+        m, x, y, xl, yl = build_ffc(z, tag)
+        m.probe_net.use_graphs = m.gallery_net.use_graphs = graphs
+        opt = FusedSGD([p for p in m.parameters() if p.requires_grad], 0.0, momentum=0.0, weight_decay=0.0, nesterov=False)
+        losses = []
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        for _ in range(5):
+            opt.zero_grad()
+            # fresh pixel noise per step: the very same image twice meets its own gallery row at cos = 1, where the Arc margin
+            # of the reference has no finite gradient (SURVEY F7)
+            xs = x + 0.1 * torch.randn(x.shape, device="cuda", generator=gen)
+            ys = y + 0.1 * torch.randn(y.shape, device="cuda", generator=gen)
+            loss = m(xs, ys, xl, yl)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        if graphs:
+            captured = [k for k, st in m.probe_net._graphs.items() if st["graph"] is not None]
+            assert any(k[0] == "fwd" for k in captured) and any(k[0] == "bwd" for k in captured), captured
+        traj.append((losses, {k: p.grad.detach().clone() for k, p in m.probe_net.named_parameters() if p.grad is not None},
+                     {k: b.detach().clone() for k, b in m.probe_net.named_buffers() if k.endswith("running_var")},
+                     m.lru.state_dict(), m._state().qp.copy()))
+    (l0, g0, r0, s0, q0), (l1, g1, r1, s1, q1) = traj
+    print("losses plain %s\n       graph %s" % (l0, l1))
+    loose = tag == "mobile"
+    assert np.isfinite(l1).all()
+    np.testing.assert_allclose(l1, l0, rtol=2e-2 if loose else 3e-3)
+    cat = lambda d: np.concatenate([d[k].float().cpu().numpy().ravel() for k in sorted(d)])
+    assert rel_l2(cat(g1), cat(g0)) <= (0.3 if loose else 5e-2)          # the bounds of test_streams_do_not_change_the_step
+    assert rel_l2(cat(r1), cat(r0)) <= 1e-3
+    assert s0 == s1 and (q0 == q1).all()
+
+
 def test_ir18_two_steps_vs_oracle():
     """A deeper net (ir18), two consecutive steps, against the float64 oracle: loss trajectory,
     LRU / queue_position state, embedding cosine."""

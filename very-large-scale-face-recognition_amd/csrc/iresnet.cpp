@@ -416,8 +416,8 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
   char* ctx = (char*)ctx_v;
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
-  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_forward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(ctx + n->sums_begin, n->sums_end - n->sums_begin, st));
+  hipError_t e = hipSuccess;
   const int B = n->B, S = n->HW0;
   auto sums_of = [&](const Bn& b) { return (double*)(ctx + b.off_sums); };
   // Every BatchNorm's batch statistics are accumulated by the kernel that PRODUCES its input (conv
@@ -476,8 +476,7 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   const int B = n->B, S = n->HW0;
   const Block& last = n->blocks.back();
   const int HWl = last.Ho * last.Wo;
-  hipError_t e0 = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, (hipStream_t)st);
-  if (e0 != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e0));
+  RUN(vlsfr_zero_bytes(ctx + n->red_begin, n->red_end - n->red_begin, st));
   // embedding tail, fc
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_feat_invstd),
@@ -508,8 +507,7 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   char* dc0 = sc.g[(cur_i + 1) % 3];
   RUN(bn_backward(n->stem_bn, sc.g[cur_i], ctx + n->off_c0, dc0, (int64_t)B * S * S, S * S, nullptr, 0, params, grads,
                   ctx, st));
-  hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(sc.stem_dw, 64 * 32 * 4, st));
   RUN(vlsfr_conv2d_wgrad_ws(&n->stem.d, dc0, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
   RUN(vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, st));
   return signal(4);
@@ -537,7 +535,8 @@ int vlsfr_iresnet_forward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1,
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
   hipStream_t s = (hipStream_t)st;
-  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, s);
+  RUN(vlsfr_zero_bytes(ctx + n->sums_begin, n->sums_end - n->sums_begin, (void*)s));
+  hipError_t e = hipSuccess;
   const Block& first = n->blocks[k0];
   char* cur = k0 > 0 ? ctx + n->blocks[k0 - 1].out : ctx + n->off_a0;
   const int64_t Min = (int64_t)n->B * first.H * first.W;
@@ -562,7 +561,8 @@ int vlsfr_iresnet_backward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
   hipStream_t s = (hipStream_t)st;
-  hipError_t e = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, s);
+  RUN(vlsfr_zero_bytes(ctx + n->red_begin, n->red_end - n->red_begin, (void*)s));
+  hipError_t e = hipSuccess;
   const Block& lastb = n->blocks[k1 - 1];
   int cur_i = 0;
   if (e == hipSuccess)
@@ -678,8 +678,7 @@ int vlsfr_iresnet_backward_overlap(const vlsfr_iresnet* n, const float* demb, co
   const int B = n->B, S = n->HW0;
   const Block& last = n->blocks.back();
   const int HWl = last.Ho * last.Wo;
-  hipError_t e0 = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, sm);
-  if (e0 != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: memset: %s", hipGetErrorString(e0));
+  RUN(vlsfr_zero_bytes(ctx + n->red_begin, n->red_end - n->red_begin, (void*)sm));
   {   // the side stream starts behind everything the main stream has done so far (forward pass, head, zeroed gradients)
     hipError_t e = hipEventRecord(ev_join, sm);
     if (e == hipSuccess) e = hipStreamWaitEvent(ss, ev_join, 0);
@@ -735,8 +734,7 @@ int vlsfr_iresnet_backward_overlap(const vlsfr_iresnet* n, const float* demb, co
   const int s_c0 = R.acquire();
   RUN(bn_backward(n->stem_bn, R.slot(s_cur), ctx + n->off_c0, R.slot(s_c0), (int64_t)B * S * S, S * S, nullptr, 0, params, grads,
                   ctx, sm));
-  hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, sm);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_overlap: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(sc.stem_dw, 64 * 32 * 4, (void*)sm));
   RUN(vlsfr_conv2d_wgrad(&n->stem.d, R.slot(s_c0), ctx + n->off_cols, sc.stem_dw, 0, sm));
   RUN(vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 32, 27, sm));
   RUN(join());

@@ -254,8 +254,7 @@ int backward_units(const vlsfr_mobilenet* n, int k_hi, int k_lo, int* cur_io, in
                           grads[u.p_g], grads[u.p_b], u.p_slope >= 0 ? grads[u.p_slope] : nullptr, 0, st));
     const char* in = u.in_unit >= 0 ? ctx + n->units[u.in_unit].a : nullptr;
     if (u.kind == STEM) {
-      hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 32 * 4, (hipStream_t)st);
-      if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward: memset: %s", hipGetErrorString(e));
+      RUN(vlsfr_zero_bytes(sc.stem_dw, 64 * 32 * 4, st));
       RUN(vlsfr_conv2d_wgrad_ws(&u.d, dc, ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
       RUN(vlsfr_unpad_add(sc.stem_dw, grads[u.p_w], 64, 32, 27, st));
       break;
@@ -323,8 +322,8 @@ int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const
   (void)scratch;
   char* ctx = (char*)ctx_v;
   const char* wc = (const char*)wcache;
-  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_forward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(ctx + n->sums_begin, n->sums_end - n->sums_begin, st));
+  hipError_t e = hipSuccess;
   for (size_t k = 0; k < n->units.size(); ++k) RUN(forward_unit(n, (int)k, x_nchw, params, running, ctx, wc, st));
   // linear1 (1x1 on the 1x1 map) -> BN over the batch -> flatten -> normalise (mobilefacenet_def.py:112-114)
   const Unit& l7 = n->units.back();
@@ -346,8 +345,7 @@ int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const 
   char* ctx = (char*)ctx_v;
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
-  hipError_t e = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_backward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(ctx + n->red_begin, n->red_end - n->red_begin, st));
   const Unit& l7 = n->units.back();
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
                       (const float*)(ctx + n->off_xhat), (const float*)(ctx + n->off_invstd), params[n->l1_g], sc.dz,
@@ -381,7 +379,8 @@ int vlsfr_mobilenet_forward_units(const vlsfr_mobilenet* n, int32_t u0, int32_t 
   char* ctx = (char*)ctx_v;
   const char* wc = (const char*)wcache;
   hipStream_t s = (hipStream_t)st;
-  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, s);
+  RUN(vlsfr_zero_bytes(ctx + n->sums_begin, n->sums_end - n->sums_begin, (void*)s));
+  hipError_t e = hipSuccess;
   const Unit& prev = n->units[u0 - 1];
   if (e == hipSuccess)
     e = hipMemcpyAsync(ctx + prev.a, x_in, (size_t)n->B * prev.Ho * prev.Wo * prev.d.Cout * 2, hipMemcpyDeviceToDevice, s);
@@ -405,7 +404,8 @@ int vlsfr_mobilenet_backward_units(const vlsfr_mobilenet* n, int32_t u0, int32_t
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
   hipStream_t s = (hipStream_t)st;
-  hipError_t e = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, s);
+  RUN(vlsfr_zero_bytes(ctx + n->red_begin, n->red_end - n->red_begin, (void*)s));
+  hipError_t e = hipSuccess;
   const Unit& lastu = n->units[u1 - 1];
   int cur = 0, pend_unit = -1, pend_buf = -1;
   if (e == hipSuccess)

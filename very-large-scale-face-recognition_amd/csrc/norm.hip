@@ -567,6 +567,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdArgs a) {
 }
 
 // y = a + b (bf16 tensors): sum of two gradient branches
+// zero fill as a KERNEL (not hipMemsetAsync): the executors' accumulator regions are cleared at the head of every pass, and a
+// pass may be replayed from a HIP graph (NativeBackbone.use_graphs) — with memset nodes in the captured chain the replays
+// produced intermittently wrong BatchNorm statistics (scripts/graph_debug.py), with a kernel node they do not
+__global__ __launch_bounds__(256) void zero_kernel(uint4* p, int64_t n16, char* tail, int ntail) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 __global__ __launch_bounds__(256) void add_bf16_kernel(const u16* p, const u16* q, u16* y, int64_t n8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     bf8 u, v;
@@ -944,6 +953,19 @@ int vlsfr_bn_backward_reduce(const void* dy, const void* x, int64_t M, int32_t C
   if (slope) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, grid, block, shb, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<0>, grid, block, shb, (hipStream_t)stream, a);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_backward_reduce");
+  return VLSFR_OK;
+}
+
+int vlsfr_zero_bytes(void* p, size_t nbytes, void* stream) {
+  if (!p || ((uintptr_t)p & 15)) return fail(VLSFR_EINVAL, "vlsfr_zero_bytes: need a 16-byte aligned pointer");
+  if (nbytes == 0) return VLSFR_OK;
+  const int64_t n16 = (int64_t)(nbytes / 16);
+  const int ntail = (int)(nbytes % 16);
+  int64_t blocks = (n16 + 256 * 4 - 1) / (256 * 4);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)p, n16, (char*)p + n16 * 16, ntail);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_zero_bytes");
   return VLSFR_OK;
 }
 

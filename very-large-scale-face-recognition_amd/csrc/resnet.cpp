@@ -306,8 +306,8 @@ int vlsfr_resnet_forward(const vlsfr_resnet* n, const float* x_nchw, const float
   char* ctx = (char*)ctx_v;
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
-  hipError_t e = hipMemsetAsync(ctx + n->sums_begin, 0, n->sums_end - n->sums_begin, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_resnet_forward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(ctx + n->sums_begin, n->sums_end - n->sums_begin, st));
+  hipError_t e = hipSuccess;
   const int B = n->B;
   auto sums_of = [&](const Bn& b) { return (double*)(ctx + b.off_sums); };
   // stem (resnet_std.py:186-189): 7x7/2 conv -> BN -> ReLU -> 3x3/2 max-pool
@@ -359,8 +359,7 @@ int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float*
   const char* wc = (const char*)wcache;
   Scratch sc = carve(n, scratch);
   const int B = n->B;
-  hipError_t e0 = hipMemsetAsync(ctx + n->red_begin, 0, n->red_end - n->red_begin, (hipStream_t)st);
-  if (e0 != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_resnet_backward: memset: %s", hipGetErrorString(e0));
+  RUN(vlsfr_zero_bytes(ctx + n->red_begin, n->red_end - n->red_begin, st));
   const Block& lastb = n->blocks.back();
   // embedding tail (features.weight is trainable here: resnet_std.py:143 does not freeze it), fc
   RUN(vlsfr_embed_bwd(demb, (const float*)(ctx + n->off_emb), (const float*)(ctx + n->off_invnorm),
@@ -408,8 +407,7 @@ int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float*
   RUN(vlsfr_maxpool3x3s2_bwd(sc.g[cur], ctx + n->off_a0, ctx + n->off_m0, t[0], B, n->Hs, n->Hs, 64, st));
   RUN(bn_backward(n, n->stem_bn, t[0], ctx + n->off_c0, t[1], (int64_t)B * n->Hs * n->Hs, n->Hs * n->Hs, 1, params, grads, ctx,
                   sc.dslope, st));
-  hipError_t e = hipMemsetAsync(sc.stem_dw, 0, 64 * 160 * 4, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_resnet_backward: memset: %s", hipGetErrorString(e));
+  RUN(vlsfr_zero_bytes(sc.stem_dw, 64 * 160 * 4, st));
   RUN(vlsfr_conv2d_wgrad_ws(&n->stem.d, t[1], ctx + n->off_cols, sc.stem_dw, 0, sc.wgrad_ws, n->wgrad_ws, st));
   return vlsfr_unpad_add(sc.stem_dw, grads[n->stem.p_w], 64, 160, 147, st);
 }

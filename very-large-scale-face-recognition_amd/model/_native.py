@@ -83,6 +83,8 @@ class NativeBackbone(nn.Module):
         self._ctx_owner = [None, None]     # weakref to the autograd ctx that still needs the buffer
         self._eval_ctx = [None, None]      # saved-activation buffers of the no-grad passes (one per concurrent chain)
         self._chain = None                 # (stream, pass index) while run_chain() is on the stack
+        self.use_graphs = False            # True: forward / backward executor calls replayed from HIP graphs (launch-bound sizes)
+        self._graphs = {}
         self._deferred = None              # zeroed stand-ins for the running statistics (begin_deferred_running)
         self._fwd_slot = 0
         self._join_queued = False
@@ -195,6 +197,40 @@ class NativeBackbone(nn.Module):
             self._scratch_alt = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._scratch_alt
 
+    GRAPH_WARMUP = 2       # eager calls per signature before its graph is captured (lazy buffers exist, LDS attributes are set)
+
+    def _launch(self, key, sig, inp, out, call):
+        """Runs call(inp, out) — one executor call: a few hundred dependent kernel launches — on the current stream, or,
+        with `use_graphs`, replays it from a HIP graph captured on the third call with the same buffers (sig: every pointer
+        the call bakes into its launches).  MobileFaceNet at batch 32 issues ~1 200 kernels of a few microseconds per step:
+        the step is bound by the launch rate, which a graph launch removes.  The input is copied into the
+        graph's own buffer; `out` is returned as a copy of the graph's output buffer.  Not to be combined with the measurement
+        hooks (they bracket launches with events on the launching stream: bench.py turns graphs off for its profiled repeats).
+        The executors clear their accumulator regions with a zero-fill KERNEL (vlsfr_zero_bytes): with hipMemsetAsync nodes in
+        the captured chain, replays gave intermittently wrong BatchNorm statistics on ROCm 7.2 (scripts/graph_debug.py)."""
+        if not self.use_graphs:
+            call(inp, out)
+            return out
+        st = self._graphs.get(key)
+        if st is None or st["sig"] != sig:
+            st = self._graphs[key] = dict(sig=sig, seen=0, graph=None)
+        if st["graph"] is None:
+            st["seen"] += 1
+            if st["seen"] <= self.GRAPH_WARMUP:
+                call(inp, out)
+                return out
+            st["inp"], st["out"] = torch.empty_like(inp), (torch.empty_like(out) if out is not None else None)
+            st["inp"].copy_(inp)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                call(st["inp"], st["out"])
+            st["graph"] = g
+        st["inp"].copy_(inp)
+        st["graph"].replay()
+        if out is not None:
+            out.copy_(st["out"])
+        return out
+
     def _run_forward(self, x, save, owner=None, slot=0, chain=None):
         """chain = (stream, k): this pass is pass k (0 / 1) of a step whose passes run side by side (FFC.embed_both) — it
         executes on `stream`, with scratch / no-grad context k of its own, and (training) leaves its running-statistics
@@ -228,10 +264,14 @@ class NativeBackbone(nn.Module):
                 run_tab = self._deferred["tabs"][k]
             else:
                 run_tab = _ptr_array(running)
-            _lib.check(fwd(h, ctypes.c_void_p(x.data_ptr()), _ptr_array(params), run_tab,
-                           ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                           ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(emb.data_ptr()), _stream()),
-                       self._cprefix + "_forward")
+            run_ptrs = None if run_tab is None else tuple(run_tab)
+            emb = self._launch(("fwd", B, str(x.device), bool(save), slot if save else k, k, run_ptrs is not None),
+                               (tuple(p.data_ptr() for p in params), run_ptrs, self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()),
+                               x, emb,
+                               lambda xin, out: _lib.check(fwd(h, ctypes.c_void_p(xin.data_ptr()), _ptr_array(params), run_tab,
+                                                               ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                                               ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(out.data_ptr()), _stream()),
+                                                           self._cprefix + "_forward"))
         if self.training:
             self._nbt_pending += 1          # num_batches_tracked is materialised lazily (flush_counters)
         self.__dict__.setdefault("_keep", {})[k] = x      # the input outlives the asynchronous pass
@@ -380,9 +420,17 @@ class NativeBackbone(nn.Module):
             return
         bwd = getattr(L, self._cprefix + "_backward")
         bwd.restype = ctypes.c_int
-        _lib.check(bwd(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
-                       ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                       ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward")
+        if signal:      # an event is recorded right behind the pass: plain launches
+            _lib.check(bwd(h, ctypes.c_void_p(demb.data_ptr()), _ptr_array(params), _ptr_array(grads),
+                           ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                           ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward")
+        else:
+            self._launch(("bwd", B, str(demb.device), slot, bool(alt)),
+                         (tuple(p.data_ptr() for p in params), tuple(g.data_ptr() if g is not None else 0 for g in grads),
+                          self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()), demb, None,
+                         lambda din, _o: _lib.check(bwd(h, ctypes.c_void_p(din.data_ptr()), _ptr_array(params), _ptr_array(grads),
+                                                        ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                                        ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward"))
         if signal:                                              # single bucket: complete when the pass is
             _lib.check(L.vlsfr_event_record(ctypes.c_void_p(self.stage_events(slot)[0]), _stream()), "vlsfr_event_record")
 
