@@ -402,6 +402,35 @@ def test_conv_one_round_tiles_of_the_256_channel_layers(N, opt, p8):
     close(st[1], (yf * yf).sum(0).cpu(), 2e-5)
 
 
+# the other launches that reach conv_igemm_p8_kernel at batch 256: a stride-2 forward (256 -> 256, 28 x 28 -> 14 x 14), and
+# MobileFaceNet's expanding pointwise convolutions onto 256 channels at 14 x 14 — ONE or TWO k-tiles, i.e. a loop that is
+# all prologue and tail
+@pytest.mark.parametrize("cin,k,stride,hw", [(256, 3, 2, 28), (128, 1, 1, 14), (64, 1, 1, 14)], ids=["3x3-stride2", "1x1-2ktiles", "1x1-1ktile"])
+def test_conv_four_phase_kernel_short_loops_and_stride(cin, k, stride, hw):
+    import ctypes
+    from vlsfr_amd import ops, _lib
+    N, cout, n, pad = 256, 256, 4, k // 2
+    gen = torch.Generator(device="cuda").manual_seed(13)
+    x = torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16)
+    w = (torch.randn(cout, k, k, cin, device="cuda", generator=gen) * 0.05).contiguous()
+    wb, _ = ops.cast_weight(w, cout, k * k, cin)
+    big, small = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad), ops.ConvDesc(n, hw, hw, cin, cout, k, k, stride, pad)
+    set_p8 = lambda v: _lib.lib().vlsfr_set_option(b"conv_p8", ctypes.c_int32(v))
+    outs = {}
+    try:
+        for p8 in (1, 0):
+            set_p8(p8)
+            stats = ops.new_sums(cout, "cuda")
+            outs[p8] = (ops.conv2d_fwd(x, wb, big, stats=stats), stats.sum(0))
+    finally:
+        set_p8(1)
+    assert torch.equal(outs[1][0], outs[0][0])                      # the one-phase kernel on the same tiles
+    for s0 in (0, 124, N - 4):
+        assert torch.equal(ops.conv2d_fwd(x[s0:s0 + n].contiguous(), wb, small), outs[1][0][s0:s0 + n])
+    close(outs[1][1][0], outs[0][1][0].cpu(), 1e-6)
+    close(outs[1][1][1], outs[0][1][1].cpu(), 1e-6)
+
+
 # ---- operators of the torchvision-style ResNet (reference model/resnet_std.py) ---------------------------------
 def test_stem7_im2col_matches_conv():
     from vlsfr_amd import ops

@@ -2335,8 +2335,8 @@ int vlsfr_conv2d_dgrad_bnred(const vlsfr_conv_desc* d, const void* dy, const voi
     a.Hf = d->H;
     a.Wf = d->W;
     if (f11) {   // only the even positions see dY: the rest of dX is zero
-      hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin * 2, st);
-      if (e != hipSuccess) return hip_fail(e, "vlsfr_conv2d_dgrad: memset");
+      // (a kernel, not hipMemsetAsync: this call sits inside backbone passes that may be captured into a HIP graph, norm.hip)
+      if (int rz = vlsfr_zero_bytes(dx, (size_t)d->N * d->H * d->W * d->Cin * 2, (void*)st)) return rz;
       a.tap_mask = 1u;
       a.tap_w = 0;
       a.cls = 1;
