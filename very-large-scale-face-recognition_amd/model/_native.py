@@ -126,6 +126,14 @@ class NativeBackbone(nn.Module):
     def _tables(self):
         """Pointer tables in the executor's order (= registration order of the reference module)."""
         params = self._plist
+        # The layout check walks every parameter (a permuted view each) and every buffer: ~1 ms of host time per call for
+        # ir100, paid six times a step.  It is repeated only when the parameter storage has visibly changed (first / last
+        # pointer: .cuda(), .to(), an optimizer re-pointing the parameters into a flat buffer) or after _apply /
+        # load_state_dict (hooks below); in-place writes (copy_, optimizer steps) keep strides and need no re-check.
+        key = (params[0].data_ptr(), params[-1].data_ptr(), len(params)) if params else None
+        cache = self.__dict__.get("_tables_cache")
+        if cache is not None and cache[0] == key:
+            return params, cache[1]
         for p in params:
             p._vlsfr_owner = self
             if p.dim() == 4 and not p.data.permute(0, 2, 3, 1).is_contiguous():
@@ -136,7 +144,18 @@ class NativeBackbone(nn.Module):
         for name, b in self.named_buffers():
             if name.endswith("running_mean") or name.endswith("running_var"):
                 running.append(b)
+        key = (params[0].data_ptr(), params[-1].data_ptr(), len(params)) if params else None
+        self.__dict__["_tables_cache"] = (key, running)
         return params, running
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_tables_cache"] = None
+        self.__dict__["_plist_cache"] = None
+        return super(NativeBackbone, self)._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__["_tables_cache"] = None
+        return super(NativeBackbone, self).load_state_dict(*args, **kwargs)
 
     def _handle(self, B, device):
         L = _lib.lib()
@@ -201,7 +220,7 @@ class NativeBackbone(nn.Module):
 
     def _launch(self, key, sig, inp, out, call):
         """Runs call(inp, out) — one executor call: a few hundred dependent kernel launches — on the current stream, or,
-        with `use_graphs`, replays it from a HIP graph captured on the third call with the same buffers (sig: every pointer
+        with `use_graphs`, replays it from a HIP graph captured on the third call with the same buffers (sig(): every pointer
         the call bakes into its launches).  MobileFaceNet at batch 32 issues ~1 200 kernels of a few microseconds per step:
         the step is bound by the launch rate, which a graph launch removes.  The input is copied into the
         graph's own buffer; `out` is returned as a copy of the graph's output buffer.  Not to be combined with the measurement
@@ -211,6 +230,7 @@ class NativeBackbone(nn.Module):
         if not self.use_graphs:
             call(inp, out)
             return out
+        sig = sig()          # (a callable: some six hundred data_ptr() calls that plain launches do not need)
         st = self._graphs.get(key)
         if st is None or st["sig"] != sig:
             st = self._graphs[key] = dict(sig=sig, seen=0, graph=None)
@@ -264,9 +284,9 @@ class NativeBackbone(nn.Module):
                 run_tab = self._deferred["tabs"][k]
             else:
                 run_tab = _ptr_array(running)
-            run_ptrs = None if run_tab is None else tuple(run_tab)
-            emb = self._launch(("fwd", B, str(x.device), bool(save), slot if save else k, k, run_ptrs is not None),
-                               (tuple(p.data_ptr() for p in params), run_ptrs, self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()),
+            emb = self._launch(("fwd", B, x.device.index, bool(save), slot if save else k, k, run_tab is not None),
+                               lambda: (tuple(p.data_ptr() for p in params), None if run_tab is None else tuple(run_tab),
+                                        self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()),
                                x, emb,
                                lambda xin, out: _lib.check(fwd(h, ctypes.c_void_p(xin.data_ptr()), _ptr_array(params), run_tab,
                                                                ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
@@ -425,9 +445,9 @@ class NativeBackbone(nn.Module):
                            ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
                            ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward")
         else:
-            self._launch(("bwd", B, str(demb.device), slot, bool(alt)),
-                         (tuple(p.data_ptr() for p in params), tuple(g.data_ptr() if g is not None else 0 for g in grads),
-                          self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()), demb, None,
+            self._launch(("bwd", B, demb.device.index, slot, bool(alt)),
+                         lambda: (tuple(p.data_ptr() for p in params), tuple(g.data_ptr() if g is not None else 0 for g in grads),
+                                  self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()), demb, None,
                          lambda din, _o: _lib.check(bwd(h, ctypes.c_void_p(din.data_ptr()), _ptr_array(params), _ptr_array(grads),
                                                         ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
                                                         ctypes.c_void_p(scratch.data_ptr()), _stream()), self._cprefix + "_backward"))
