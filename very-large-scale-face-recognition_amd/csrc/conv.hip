@@ -1022,15 +1022,16 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
 //   phase:   { ds_read of the quadrant's new operand sub-block ; stage ONE half-tile of a later k-tile (2 LDS-DMA instructions) }
 //            s_barrier ; lgkmcnt(0) ; setprio(1) 16 x MFMA setprio(0) ; s_barrier
 // and the two groups of four waves (one wave per SIMD each) run ONE BARRIER APART, so on every SIMD one wave multiplies while the
-// other reads LDS and issues DMA.  The DMA is never drained inside the loop: one counted vmcnt(4) per k-tile leaves the two
+// other reads LDS and issues DMA.  The DMA is never drained inside the loop: one counted vmcnt(6) per k-tile leaves the three
 // half-tiles staged last in flight across the barriers.
 //   LDS: two k-tile buffers of [A half 0 | A half 1 | B half 0 | B half 1], 128-byte rows, chunks XOR-swizzled with (row & 7).
 //   The halves are laid out by PHASE OF FIRST USE, not by tile row: A half 0 holds MFMA row tiles i = 0, 1 of every wave
 //   (read in phase 1), half 1 tiles i = 2, 3 (phase 2); B half 0 holds pixel tiles j = 0..3 of every wave (phase 1), half 1
 //   tiles j = 4.. (phase 3) — so a half is dead for ALL waves two phases after its read and can be restaged then:
-//     tile u:  A0 staged in phase 3 of tile u - 2, B0 in phase 4 of u - 2, A1 in phase 1 of u - 1, B1 in phase 2 of u - 1;
-//     phase 4 of tile u - 1 waits vmcnt(4): everything but A0 / B0 of tile u + 1 has landed, i.e. all of tile u, one phase (two
-//     barriers) before its first read.  (A counted wait in EVERY phase with the last four half-tiles left in flight — a whole
+//     tile u:  A0 staged in phase 3 of tile u - 2, B0 and A1 in phase 4 of u - 2 (the phase that reads nothing), B1 in phase 2 of
+//     u - 1, nothing in phase 1 (which issues 12 of a tile's 22 - 24 reads: a DMA piece issued among them costs 100 - 185 cycles);
+//     phase 4 of tile u - 1 waits vmcnt(6): everything but A0 / B0 / A1 of tile u + 1 has landed, i.e. all of tile u, one phase
+//     (two barriers) before its first read.  (A counted wait in EVERY phase with the last four half-tiles left in flight — a whole
 //     k-tile of latency for each — measured 76.6 us against 63.6 us for this form on the 256 -> 256 14 x 14 layer.)
 //   Quadrants: phase 1 acc[0..1][0..3] (A0 B0), 2 acc[2..3][0..3] (A1 B0), 3 acc[2..3][4..] (A1 B1), 4 acc[0..1][4..] (A0 B1):
 //   every accumulator sees k in the order of the default kernel (bit-identical results).
@@ -1174,7 +1175,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
   if (nk > 1) {
     stage_a(0, c1_j, c1_c, 1);
     stage_b(0, c1_j, c1_c, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    stage_a(1, c1_j, c1_c, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -1218,8 +1220,7 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
       fb[kk][3] = lds_read128_asm<48 * RSB>(b);
     }
     const bool dma = !(a.dbg & 32);                      // diagnostic: no DMA after the prologue
-    if (more1 && dma) stage_a(1, c1_j, c1_c, buf ^ 1);
-    quad(I_{}, I_{}, std::integral_constant<int, NT0>{});
+    quad(I_{}, I_{}, std::integral_constant<int, NT0>{});   // (nothing staged in the phase that issues 12 of the tile's reads)
     // ---- phase 2: A sub-block 1
     fa[0][2] = lds_read128_asm<128 * RSB>(rA0);
     fa[0][3] = lds_read128_asm<128 * RSB + 16 * RSB>(rA0);
@@ -1241,7 +1242,8 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
     // ---- phase 4: no new operand; the k-tile's one counted wait
     if (more2 && dma) {
       stage_b(0, c2_j, c2_c, buf);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all of tile t + 1 has landed; A0 / B0 of tile t + 2 stay in flight
+      stage_a(1, c2_j, c2_c, buf);                        // A half 1 of this buffer was last read in phase 2
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all of tile t + 1 has landed; A0 / B0 / A1 of tile t + 2 stay in flight
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
