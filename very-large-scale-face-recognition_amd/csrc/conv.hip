@@ -104,6 +104,9 @@ int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 wor
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
 int g_conv_p8 = 1;           // "conv_p8": the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the full 256-channel one-round tiles
+int g_tile256_min = 129;     // "tile256_min": the one-round 8-wave tiles are taken from 256 * this many pixels on, i.e. as soon as the 128 x 128 tiling
+                             // (2 cout tiles x P / 128) no longer fits the 512 resident slots: batch 192, 37 632 pixels: 60.7 vs 68.9 us; batch 160
+                             // (490 tiles of 128 x 128, one round): 43.8 vs 58.8 us the other way
 int g_tile224 = 1;           // "tile224": 256 x 224 tiles where those still make one round of the 256 CUs (ir100 at batch 256: 224 tiles, not 196)
 int g_tile256 = 1;           // "tile256": 256 x 256 tiles for the 256-channel layers whose pixel count makes one round of them (run_igemm)
 int g_bnred_all = 0;         // "bnred_all": 1 = the fused BatchNorm-backward reduction on every eligible launch (default: where it pays)
@@ -2000,7 +2003,7 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   // the default LDS-DMA variant's per-shape choices (decided here so that the timing bracket knows its family)
   const bool variant_default = g_use_glds == VLSFR_DEFAULT_CONV_VARIANT;
   const bool big_tile = a.Mrows >= 128 && wg_big >= g_small_tile_wgs;
-  const bool tile256_here = glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * 160 &&
+  const bool tile256_here = glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
                             P <= 256 * 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
   const bool red_here = glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
                         (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) && (g_bnred_all || (big_tile && !a.cls));
@@ -2138,6 +2141,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "conv_p8")) {
     g_conv_p8 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "tile256_min")) {
+    g_tile256_min = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "tile224")) {
