@@ -35,7 +35,7 @@ for cin, cout, k, stride, h, cnt in SHAPES:
     dw = torch.zeros(cout, k, k, cin, device="cuda")
     stats = ops.new_sums(cout, "cuda")
     fl = 2.0 * B * ho * ho * cout * k * k * cin
-    tf = timeit(lambda: ops.conv2d_fwd(x, w, d, stats=stats))
+    tf = timeit(lambda: ops.conv2d_fwd(x, w, d, stats=None if os.environ.get("NOSTATS") else stats))
     td = timeit(lambda: ops.conv2d_dgrad(dy, wT, d))
     tw = timeit(lambda: ops.conv2d_wgrad_ws(dy, x, d, dw=dw)) if os.environ.get("WS") else timeit(lambda: ops.conv2d_wgrad(dy, x, d, dw=dw))
     ms = cnt * (4 * tf + 2 * td + 2 * tw) * 1e3

@@ -431,6 +431,56 @@ def test_conv_four_phase_kernel_short_loops_and_stride(cin, k, stride, hw):
     close(outs[1][1][1], outs[0][1][1].cpu(), 1e-6)
 
 
+# conv_igemm_hp8_kernel (round 4): the 3x3 / stride-1 layers on the four-phase schedule with the pixel operand as a halo'd
+# patch in LDS — 256-row x 224-pixel tiles (256 / 512 output channels) and 128-row x 448-pixel tiles (128 output channels).
+# Same accumulation order as the default kernel: every result must be bit-identical to it, for the forward pass (with the
+# fused BatchNorm statistics) and the input gradient, with full tiles, a ragged last tile, tiles that start in the middle of a
+# line (W does not divide the tile: the patch then carries W + 1 halo rows) and tiles that span several images.
+@pytest.mark.parametrize("cin,cout,hw,N", [(256, 256, 14, 256), (256, 256, 14, 37), (128, 128, 28, 64), (128, 128, 28, 9),
+                                           (256, 256, 10, 20), (128, 128, 12, 30), (128, 256, 7, 40), (64, 128, 28, 7), (256, 512, 14, 16)],
+                         ids=["256ch-14-exact", "256ch-14-ragged", "128ch-28-exact", "128ch-28-ragged", "256ch-10-unaligned",
+                              "128ch-12-unaligned", "256ch-7-multi-image", "64to128-28", "256to512-14"])
+def test_conv_halo_patch_four_phase_kernel_is_bit_identical(cin, cout, hw, N):
+    import ctypes
+    from vlsfr_amd import ops, _lib
+    k, n = 3, min(4, N)
+    gen = torch.Generator(device="cuda").manual_seed(17 + hw + cin)
+    x = torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16)
+    dy = torch.randn(N, hw, hw, cout, device="cuda", generator=gen).to(torch.bfloat16)
+    w = (torch.randn(cout, k, k, cin, device="cuda", generator=gen) * 0.05).contiguous()
+    wb, wT = ops.cast_weight(w, cout, k * k, cin)
+    big, small = ops.ConvDesc(N, hw, hw, cin, cout, k, k, 1, 1), ops.ConvDesc(n, hw, hw, cin, cout, k, k, 1, 1)
+    setopt = lambda name, v: _lib.lib().vlsfr_set_option(name, ctypes.c_int32(v))
+    outs = {}
+    try:
+        setopt(b"hp8_fill", 0)                   # take the kernels whatever share of the chip their tiles fill
+        # 2: conv_igemm_hw4_kernel (one wave per SIMD, software-pipelined: the default), 1: conv_igemm_hp8_kernel (four phases), 0: round-3 kernels
+        for mode in (2, 1, 0):
+            setopt(b"conv_hp8", 1 if mode else 0)
+            setopt(b"conv_hw4", 1 if mode == 2 else 0)
+            stats = ops.new_sums(cout, "cuda")
+            outs[mode] = (ops.conv2d_fwd(x, wb, big, stats=stats), ops.conv2d_dgrad(dy, wT, big), stats.sum(0))
+            if mode:                             # LDS hand-offs that were wrong would be timing-dependent: the same launch, repeatedly
+                for _ in range(8):
+                    assert torch.equal(ops.conv2d_fwd(x, wb, big), outs[mode][0]) and torch.equal(ops.conv2d_dgrad(dy, wT, big), outs[mode][1])
+    finally:
+        setopt(b"conv_hp8", 1)
+        setopt(b"conv_hw4", 1)
+        setopt(b"hp8_fill", 80)
+    assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[2][1], outs[0][1])
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    for s0 in sorted({0, N // 2, N - n}):       # and the small-batch kernel on slices (a convolution is independent per image)
+        assert torch.equal(ops.conv2d_fwd(x[s0:s0 + n].contiguous(), wb, small), outs[1][0][s0:s0 + n])
+        assert torch.equal(ops.conv2d_dgrad(dy[s0:s0 + n].contiguous(), wT, small), outs[1][1][s0:s0 + n])
+    yf = outs[1][0].double().reshape(-1, cout)
+    close(outs[1][2][0], yf.sum(0).cpu(), 2e-5)
+    close(outs[1][2][1], (yf * yf).sum(0).cpu(), 2e-5)
+    # against PyTorch on the host (bf16 operands, fp32 accumulation), a few images
+    xr = x[:n].float().cpu().permute(0, 3, 1, 2)
+    y_ref = F.conv2d(xr, bf(w.cpu().permute(0, 3, 1, 2)), None, 1, 1)
+    close(outs[1][0][:n].permute(0, 3, 1, 2), bf(y_ref), 1e-2)
+
+
 # ---- operators of the torchvision-style ResNet (reference model/resnet_std.py) ---------------------------------
 def test_stem7_im2col_matches_conv():
     from vlsfr_amd import ops

@@ -104,6 +104,10 @@ int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 wor
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
 int g_conv_p8 = 1;           // "conv_p8": the four-phases-per-k-tile schedule (conv_igemm_p8_kernel) on the full 256-channel one-round tiles
+int g_conv_hp8 = 1;          // "conv_hp8": the halo-patch four-phase kernel (conv_igemm_hp8_kernel) on the 3x3 / stride-1 layers whose tiles fill the chip:
+                             // 1 = 256-row and 128-row tiles (default), 2 = 256-row tiles only, 3 = 128-row tiles only, 0 = off
+int g_conv_hw4 = 1;          // "conv_hw4": the one-wave-per-SIMD software-pipelined form of that kernel (conv_igemm_hw4_kernel) where conv_hp8 applies
+int g_hp8_fill = 80;         // "hp8_fill": least percentage of the workgroup slots of its rounds (256 per round) that conv_igemm_hp8_kernel must fill
 int g_tile256_min = 129;     // "tile256_min": the one-round 8-wave tiles are taken from 256 * this many pixels on, i.e. as soon as the 128 x 128 tiling
                              // (2 cout tiles x P / 128) no longer fits the 512 resident slots: batch 192, 37 632 pixels: 60.7 vs 68.9 us; batch 160
                              // (490 tiles of 128 x 128, one round): 43.8 vs 58.8 us the other way
@@ -1265,6 +1269,628 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_p8_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_hp8_kernel -- 3x3 / stride 1 / pad 1 convolutions (forward and input gradient) on the four-phase schedule of
+// conv_igemm_p8_kernel, with the PIXEL operand held in LDS as one halo'd patch per 64-channel chunk (the idea of
+// conv_igemm_halo_kernel below) instead of nine shifted copies staged tap by tap.
+// Why: what a CU can pull through its vector L1 into LDS is 64 B / clk.  A 128 x 128 x 64 k-tile costs 32 KiB = 512 clk of that
+// path against 512 clk of MFMA per SIMD — the 4-wave kernel is load-path-bound by construction; the 256 x 224 four-phase tile
+// costs 60 KiB per 1 792 MFMA clk.  With the patch, a k-tile (one filter tap of one chunk) stages only its weight tile
+// (BM x 64: 32 or 16 KiB) plus 1/9 of the next chunk's patch: 36 KiB (BM = 256, 224 pixels) or 23 KiB (BM = 128, 448 pixels)
+// per 1 792 MFMA clk, and the DMA pieces a wave issues per k-tile drop from 7.5 to 4.5 / 3.
+//   tile: BM output channels (256: waves 4 x 2; 128: waves 2 x 4) x BN = WN * NT * 16 pixels, every wave 64 x (NT * 16).
+//   BM = 128 is what the 128-channel 28 x 28 layers needed: their 128 x 128 tiles are bound by the load path (above) and run
+//   3.06 rounds on the 512 resident slots; 128 x 448 tiles are 448 workgroups of the four-phase loop.
+//   LDS: [A buffer 0 | A buffer 1 | patch 0 | patch 1 | zero row]; A buffers = [half 0 | half 1] by phase of first use as in
+//   conv_igemm_p8_kernel; patch = rows q0 .. q0 + PR - 1 of the flattened (n, h, w) tensor, 128 B (64 channels) per row,
+//   16-byte chunks XOR-swizzled with the patch row.  q0 = p0 - (W + 1), or p0 - W when every tile starts a line (BN % W == 0:
+//   the corner neighbours of the first / last pixel are then never valid) — that is what lets 448 + 2 x 28 rows fit twice.
+//   Tap (r, s) of a chunk reads fragment rows lead + d + pixel, d = +-((r - 1) W + (s - 1)); a lane whose pixel has no such
+//   neighbour (image border) is pointed at the zero row (one select per fragment, validity bits per pixel from the prologue).
+//   Per k-tile u (tap t of chunk c), per wave:  phase 1 reads A half 0 + pixel tiles 0..3; phase 2 reads A half 1 and stages
+//   one piece of chunk c + 1's patch (taps 0..7: 8 x 8 = 64 pieces cover 512 rows); phase 3 reads pixel tiles 4.. and stages A
+//   half 0 of tile u + 2; phase 4 stages A half 1 of u + 2 and waits (counted) for everything issued before this tap: all of
+//   A(u + 1) — and, at a chunk's last tap, which issues no patch piece, the whole next patch.
+// The accumulation order (chunk outer, tap inner, two 32-deep steps per k-tile) is conv_igemm_glds_kernel's: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+// DIAG (diagnostic instantiations): 1 = clock stamps (vlsfr_conv_trace), 2 = no border selects (conv_dbg 256: wrong at image borders, timing only)
+template <int BM, int NT, int DIAG = 0>
+__global__ __launch_bounds__(512, 1) void conv_igemm_hp8_kernel(ConvArgs a, int PR, int lead) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool TRACE = DIAG == 1;
+  constexpr int BK = 64, NW = 8, WM = BM / 64, WN = NW / WM;
+  constexpr int MT = 4, NT0 = 4, NT1 = NT - NT0;
+  constexpr int BN = WN * NT * 16;
+  constexpr int RSB = 128;
+  constexpr int AH = BM / 2;                 // rows of an A half
+  constexpr int PA = AH / 64;                // LDS-DMA pieces per wave and A half (8 rows each, 8 waves)
+  constexpr int ASTAGE = BM * RSB;
+  constexpr int OOB = (int)0x80000000;
+  static_assert((BM == 256 || BM == 128) && NT1 >= 1 && NT1 <= 4, "tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PATCH = PR * RSB;
+  const int NPI = PR >> 3;                    // DMA pieces per patch (<= 64)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN, grp = wave >> 2;
+  const int P = a.Nimg * a.H * a.W;           // stride 1: output pixels = input pixels
+  const int K = 9 * a.C;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd) {
+    const int g = xcd_major_id(blockIdx.x, a.gx * a.gy);
+    bx = g / a.gy;
+    by = g - bx * a.gy;
+  }
+  const int m0 = by * BM, p0 = bx * BN;
+  const int nchunk = a.C / BK;
+  const int nk = 9 * nchunk;
+  const bool fwd = a.mode == 0;
+
+  const int rsub = lane >> 3;
+  const int lchunk = (lane & 7) ^ rsub;
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Mrows * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)P * a.C * 2), 0x00020000);
+  // A: piece e of half hh covers rows 8 (8 e + wave) .. + 7 of that half; half hh holds, per wave row, MFMA row tiles 2 hh, 2 hh + 1
+  int a_off[2 * PA];
+#pragma unroll
+  for (int i = 0; i < 2 * PA; ++i) {
+    const int hh = i / PA, e = i % PA;
+    const int rem = (e * 8 + wave) * 8 + rsub;
+    const int m = m0 + (rem >> 5) * 64 + ((hh << 1) | ((rem >> 4) & 1)) * 16 + (rem & 15);
+    a_off[i] = m < a.Mrows ? (m * K + lchunk * 8) * 2 : OOB;
+  }
+  auto stage_a = [&](int hh, int k0, int buf) {
+    char* st = smem + buf * ASTAGE + hh * (AH * RSB);
+#pragma unroll
+    for (int e = 0; e < PA; ++e)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(st + (e * 8 + wave) * 1024), 16, a_off[hh * PA + e], k0 * 2, 0, 0);
+  };
+  // the weight tile of k-tile 0 goes out before anything else is worked out
+  stage_a(0, 0, 0);
+  stage_a(1, 0, 0);
+  // patch: piece x covers rows 8 x .. 8 x + 7; this lane's row of piece 0 and its byte offset in chunk 0
+  char* const sP = smem + 2 * ASTAGE;
+  const int q0 = p0 - lead;
+  const int rowbytes = a.C * 2;
+  const int pq = q0 + rsub;                                   // flattened pixel of this lane's row of piece 0 (may be negative)
+  const int pq_off = pq * rowbytes + lchunk * 16;            // (only used when the row is valid)
+  auto stage_p = [&](int x, int cbyte, int pbuf) {           // x wave-uniform, < NPI
+    const int q = pq + x * 8;
+    const int off = (unsigned)q < (unsigned)P ? pq_off + x * 8 * rowbytes + cbyte : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(sP + pbuf * PATCH + x * 1024), 16, off, 0, 0, 0);
+  };
+  for (int x = wave; x < NPI; x += NW) stage_p(x, 0, 0);
+  if (tid < 32) ((float*)(sP + 2 * PATCH))[tid] = 0.f;        // the zero row (visible after the first barrier)
+  int nprol = 0;                                               // pieces of k-tile 1 in flight behind the prologue's wait
+  if (nk > 1) {
+    const int k1 = nchunk > 0 ? a.C : 0;                       // k-tile 1 = tap 1 of chunk 0 (nk >= 9 always)
+    stage_a(0, k1, 1);
+    stage_a(1, k1, 1);
+    nprol = 2 * PA;
+  }
+
+  // ---- validity bits (bit tap = 3 r + s) of the NT pixels whose fragments this lane reads: one division pair, then carries
+  uint32_t fmask[NT];
+  {
+    const int HW = a.H * a.W;
+    int p = p0 + wn * (NT * 16) + r16;
+    const int pc = p < P ? p : (P > 0 ? P - 1 : 0);
+    int n = pc / HW;
+    const int rem = pc - n * HW;
+    int ho = rem / a.W;
+    int wo = rem - ho * a.W;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      uint32_t vh = 0, vw = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int dd = fwd ? r - 1 : 1 - r;
+        vh |= ((unsigned)(ho + dd) < (unsigned)a.H) ? (1u << r) : 0u;
+        vw |= ((unsigned)(wo + dd) < (unsigned)a.W) ? (1u << r) : 0u;
+      }
+      const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << 3 : 0u) | ((vh & 4u) ? vw << 6 : 0u);
+      fmask[j] = p < P ? mask : 0u;
+      p += 16;
+      wo += 16;
+      while (wo >= a.W) {
+        wo -= a.W;
+        if (++ho >= a.H) ho = 0;     // (the image index is not needed: validity depends on (ho, wo) only)
+      }
+    }
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const uint32_t xk0 = (uint32_t)((h ^ (r16 & 7)) << 4), xk1 = (uint32_t)(((4 + h) ^ (r16 & 7)) << 4);
+  const uint32_t rowA = lds0 + (uint32_t)((wm * 32 + r16) * RSB);
+  const uint32_t ldsP = lds0 + (uint32_t)(2 * ASTAGE);
+  const uint32_t zaddr = ldsP + (uint32_t)(2 * PATCH);
+  const int rowb0 = lead + wn * (NT * 16) + r16;               // patch row of this lane's pixel of pixel tile 0, tap shift 0
+
+  if (nprol) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (grp == 1) __builtin_amdgcn_s_barrier();   // the second group runs one barrier behind the first
+
+  bf16x8 fa[2][4], fb[2][4];
+  // TRACE (diagnostic instantiation, vlsfr_conv_trace): clock stamps of waves 0 and 4 of one workgroup, 16 per k-tile:
+  // per phase [R section starts, R section issued (and its reads returned: the stamp itself waits on lgkmcnt), barrier passed,
+  // MFMAs issued]; layout [2 groups][64 k-tiles][16]
+  int tr_u = 0, tr_ph = 0;
+  const bool tr_on = TRACE && a.trace && bx == 7 && by == 0 && (wave & 3) == 0;
+  long long* const trp = TRACE && a.trace ? a.trace + (wave >> 2) * 64 * 16 : nullptr;
+  auto stamp = [&](int k) {
+    if constexpr (TRACE) {
+      if (tr_on && tr_u < 64) {
+        const long long c_ = (long long)__builtin_readcyclecounter();
+        if (lane == 0) __builtin_nontemporal_store(c_, trp + tr_u * 16 + tr_ph * 4 + k);
+      }
+    }
+  };
+  auto quad = [&](auto i0_tag, auto j0_tag, auto nj_tag) {
+    constexpr int I0 = decltype(i0_tag)::value, J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
+    stamp(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[I0 + i][J0 + j] = mfma16(fa[kk][I0 + i], fb[kk][j], acc[I0 + i][J0 + j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(3);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);   // the next phase's address arithmetic stays behind the barrier (beside the partner's MFMAs)
+    if constexpr (TRACE) {
+      if (++tr_ph == 4) {
+        tr_ph = 0;
+        ++tr_u;
+      }
+      stamp(0);
+    }
+  };
+  // pixel tiles J0 .. J0 + NJ - 1 of this tap into fb: patch rows rowb + 16 j, or the zero row where the neighbour does not exist
+  auto read_b = [&](auto j0_tag, auto nj_tag, uint32_t pbase, uint32_t xb0, uint32_t xb1, uint32_t bit) {
+    constexpr int J0 = decltype(j0_tag)::value, NJ = decltype(nj_tag)::value;
+    static_for<NJ>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const uint32_t sel = (DIAG == 2 || (fmask[J0 + j] & bit)) ? pbase + (uint32_t)((J0 + j) * 16 * RSB) : zaddr;
+      fb[0][j] = lds_read128_asm<0>(sel + xb0);
+      fb[1][j] = lds_read128_asm<0>(sel + xb1);
+    });
+  };
+  using I_ = std::integral_constant<int, 0>;
+  const bool dma = !(a.dbg & 32);                       // diagnostic: no DMA after the prologue
+  stamp(0);
+  int t = 0, tr = 0, ts = 0, c = 0;                     // tap (= 3 tr + ts) and chunk of k-tile u
+  for (int u = 0; u < nk; ++u) {
+    const int buf = u & 1;
+    const uint32_t sb = (uint32_t)(buf * ASTAGE);
+    const bool more2 = u + 2 < nk;
+    // k-tile u + 2: tap t + 2 of this chunk, or tap t - 7 of the next
+    const int t2 = t + 2 >= 9 ? t - 7 : t + 2;
+    const int k2 = t2 * a.C + (t + 2 >= 9 ? c + 1 : c) * BK;
+    const int d = fwd ? (tr - 1) * a.W + (ts - 1) : (1 - tr) * a.W + (1 - ts);
+    const int rowb = rowb0 + d;
+    const uint32_t key = (uint32_t)(rowb & 7);
+    const uint32_t xb0 = ((uint32_t)h ^ key) << 4, xb1 = ((uint32_t)(4 + h) ^ key) << 4;
+    const uint32_t pbase = ldsP + (uint32_t)((c & 1) * PATCH) + (uint32_t)(rowb * RSB);
+    const uint32_t bit = 1u << t;
+    // ---- phase 1: A half 0, pixel tiles 0..3
+    const uint32_t rA0 = rowA + sb + xk0, rA1 = rowA + sb + xk1;
+    fa[0][0] = lds_read128_asm<0>(rA0);
+    fa[0][1] = lds_read128_asm<16 * RSB>(rA0);
+    fa[1][0] = lds_read128_asm<0>(rA1);
+    fa[1][1] = lds_read128_asm<16 * RSB>(rA1);
+    read_b(I_{}, std::integral_constant<int, NT0>{}, pbase, xb0, xb1, bit);
+    quad(I_{}, I_{}, std::integral_constant<int, NT0>{});
+    // ---- phase 2: A half 1; one piece of the next chunk's patch
+    fa[0][2] = lds_read128_asm<AH * RSB>(rA0);
+    fa[0][3] = lds_read128_asm<AH * RSB + 16 * RSB>(rA0);
+    fa[1][2] = lds_read128_asm<AH * RSB>(rA1);
+    fa[1][3] = lds_read128_asm<AH * RSB + 16 * RSB>(rA1);
+    const int px = t * NW + wave;
+    const bool piece = dma && t < 8 && c + 1 < nchunk && px < NPI;   // wave-uniform
+    if (piece) stage_p(px, (c + 1) * (BK * 2), (c + 1) & 1);
+    quad(std::integral_constant<int, 2>{}, I_{}, std::integral_constant<int, NT0>{});
+    // ---- phase 3: pixel tiles 4.. (over tiles 0..3's registers); A half 0 of k-tile u + 2 (this buffer's half 0 was last read in phase 1)
+    read_b(std::integral_constant<int, NT0>{}, std::integral_constant<int, NT1>{}, pbase, xb0, xb1, bit);
+    if (more2 && dma) stage_a(0, k2, buf);
+    quad(std::integral_constant<int, 2>{}, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT1>{});
+    // ---- phase 4: A half 1 of k-tile u + 2; the k-tile's one counted wait: everything issued before this tap has landed
+    if (more2 && dma) {
+      stage_a(1, k2, buf);
+      if (piece) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PA) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    quad(I_{}, std::integral_constant<int, NT0>{}, std::integral_constant<int, NT1>{});
+    if (++ts == 3) {
+      ts = 0;
+      ++tr;
+    }
+    if (++t == 9) {
+      t = tr = ts = 0;
+      ++c;
+    }
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();   // both groups past their last LDS read: the epilogue reuses the ring
+  if (a.dbg & 64) {                             // diagnostic: no epilogue
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0] + acc[3][NT - 1][3] + acc[1][2][1] + acc[2][5][2];
+    return;
+  }
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, false>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
+#endif
+}
+
+// MFMA with the accumulator pinned in the accumulator half of the register file ("+a"): with 224 accumulator registers and a
+// 120-register fragment double buffer per wave the compiler otherwise shuttles accumulator tiles between the two halves every
+// iteration (hundreds of v_accvgpr moves per k-tile).  Inline asm also fixes the instruction's place in the stream.
+__device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_igemm_hw4_kernel -- the same halo-patch operand path with ONE WAVE PER SIMD and a single software-pipelined instruction
+// stream instead of two waves per SIMD trading places at barriers.  What the stamps of conv_igemm_hp8_kernel showed
+// (scripts/hp8_trace.py, profiles/r04_hp8_trace.txt): its LDS-read / select sections take 450 - 600 cycles beside MFMA sections of
+// 192 - 256, and even the bare four-phase loop pays ~175 cycles per barrier interval, eight times per k-tile — the matrix pipes
+// are busy about half the time.  Here:
+//   * 4 waves (256 threads, one workgroup per CU, the whole 512-register file per wave): every wave owns 128 channels x (NT * 16)
+//     pixels = 8 x NT accumulator tiles — 15 fragment reads per 56 MFMAs instead of 11 per 28, and half as many waves repeat the
+//     per-lane border selects and the LDS-DMA address work.
+//   * a k-tile (one filter tap of one 64-channel chunk) is two steps of 56 MFMAs (k = 0..31, 32..63).  The fragments of step
+//     s + 1 are read from LDS BETWEEN the MFMAs of step s into the other half of a double register buffer (one ds_read, or two
+//     VALU, or one LDS-DMA piece per MFMA gap — each gap has 8 issue cycles the MFMA does not hold), the border selects of the
+//     next tap are computed in the gaps after them, and the LDS-DMA of the weight tile of k-tile u + 2 and of this tap's piece of
+//     the next chunk's patch are issued in the first gaps of the second step.  The order is pinned gap by gap
+//     (__builtin_amdgcn_sched_barrier between them): nothing is left to the scheduler's idea of a good interleave.
+//   * ONE barrier per k-tile (head of the second step): behind it every wave has finished reading weight buffer u & 1's first
+//     half-step... precisely: the reads of step 2u + 1 were issued during step 2u and have returned (lgkmcnt(0)), so buffer u & 1
+//     is dead for everyone and takes tile u + 2; the wave's own DMA of the previous k-tile is drained (vmcnt(0): it had a whole
+//     k-tile, ~1 800 cycles, to land) in front of the barrier, so behind it tile u + 1 — read from step 2u + 1 on — is complete.
+//   LDS: [A buffer 0 | A buffer 1 | patch 0 | patch 1 | zero row], weight rows in natural order (wave row wm reads rows
+//   128 wm + 16 i + r16), everything else as in conv_igemm_hp8_kernel.  Same accumulation order: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+// DIAG = 1 (diagnostic instantiation, vlsfr_conv_trace): wave 0 of one workgroup stamps the shader clock at the head of both steps of
+// every k-tile ([64][2]) and the 100 MHz real-time clock around the loop ([128], [129]): cycles per step and the clock the chip holds.
+template <int BM, int NT, int PPW, int DIAG = 0>
+__global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int PR, int lead) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool TRACE = DIAG == 1;
+  constexpr int BK = 64, NW = 4, WM = BM / 128, WN = NW / WM, MT = 8;
+  constexpr int BN = WN * NT * 16;
+  constexpr int RSB = 128;
+  constexpr int ASTAGE = BM * RSB;
+  constexpr int PA = BM / 8 / NW;            // LDS-DMA pieces of a weight tile per wave (8 rows each): 8 or 4
+  constexpr int NMF = MT * NT;               // MFMAs per step
+  constexpr int OOB = (int)0x80000000;
+  static_assert((BM == 256 || BM == 128) && NT >= 4 && NT <= 8 && (PPW == 1 || PPW == 2), "tile");
+  constexpr int DSTEP = BM == 256 ? 5 : 8;   // MFMA gaps between two LDS-DMA pieces of the second step
+  static_assert((PA + PPW - 1) * DSTEP < NMF && (PA + PPW - 1) * DSTEP + 6 <= NMF && PA + PPW + MT + NT + 5 <= NMF && MT + NT + 4 + 2 * NT + 3 * PPW <= NMF, "the side operations of a step fit its MFMA gaps");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int PATCH = PR * RSB;
+  const int NPI = PR >> 3;                    // DMA pieces per patch (<= 32 PPW)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, h = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int P = a.Nimg * a.H * a.W;           // stride 1: output pixels = input pixels
+  const int K = 9 * a.C;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd) {
+    const int g = xcd_major_id(blockIdx.x, a.gx * a.gy);
+    bx = g / a.gy;
+    by = g - bx * a.gy;
+  }
+  const int m0 = by * BM, p0 = bx * BN;
+  const int nchunk = a.C / BK;
+  const int nk = 9 * nchunk;
+  const bool fwd = a.mode == 0;
+  if constexpr (TRACE) {   // [130]: kernel entry, [131] (below): behind the epilogue — real-time clock, 100 MHz
+    if (a.trace && bx == 7 && by == 0 && tid == 0) __builtin_nontemporal_store((long long)__builtin_amdgcn_s_memrealtime(), a.trace + 130);
+  }
+
+  const int rsub = lane >> 3;
+  const int lchunk = (lane & 7) ^ rsub;
+  const __amdgpu_buffer_rsrc_t rs_w =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Mrows * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)P * a.C * 2), 0x00020000);
+  // weight tile: piece x = e * NW + wave covers rows 8 x .. 8 x + 7 (Mrows % BM == 0: run_igemm); one per-lane offset, the rest scalar
+  const int a_off0 = ((m0 + 8 * wave + rsub) * K + lchunk * 8) * 2;
+  const int a_estep = NW * 8 * K * 2;
+  auto stage_a1 = [&](int e, int k0, int buf, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + buf * ASTAGE + (e * NW + wave) * 1024), 16, voff,
+                                             k0 * 2 + e * a_estep, 0, 0);
+  };
+  for (int e = 0; e < PA; ++e) stage_a1(e, 0, 0, a_off0);
+  char* const sP = smem + 2 * ASTAGE;
+  const int q0 = p0 - lead;
+  const int rowbytes = a.C * 2;
+  const int pq = q0 + rsub;
+  const int pq_off = pq * rowbytes + lchunk * 16;
+  // piece x (wave-uniform) of a patch; due == false: nothing to fetch — the instruction still issues (no branch in the stream), with an
+  // out-of-range offset (no memory traffic, zeros) into the dump area behind the zero row
+  auto stage_p = [&](int x, int cbyte, int pbuf, bool due) {
+    const int q = pq + x * 8;
+    const int off = (due && (unsigned)q < (unsigned)P) ? pq_off + x * 8 * rowbytes + cbyte : OOB;
+    char* dst = due ? sP + pbuf * PATCH + x * 1024 : sP + 2 * PATCH + 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)dst, 16, off, 0, 0, 0);
+  };
+  for (int x = wave; x < NPI; x += NW) stage_p(x, 0, 0, true);
+  if (tid < 32) ((float*)(sP + 2 * PATCH))[tid] = 0.f;        // the zero row
+  if (nk > 1)
+    for (int e = 0; e < PA; ++e) stage_a1(e, a.C, 1, a_off0);  // k-tile 1 = tap 1 of chunk 0
+
+  // ---- validity bits (bit tap = 3 r + s) of the NT pixels whose fragments this lane reads
+  uint32_t fmask[NT];
+  {
+    const int HW = a.H * a.W;
+    int p = p0 + wn * (NT * 16) + r16;
+    const int pc = p < P ? p : (P > 0 ? P - 1 : 0);
+    const int n = pc / HW;
+    const int rem = pc - n * HW;
+    int ho = rem / a.W;
+    int wo = rem - ho * a.W;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      uint32_t vh = 0, vw = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int dd = fwd ? r - 1 : 1 - r;
+        vh |= ((unsigned)(ho + dd) < (unsigned)a.H) ? (1u << r) : 0u;
+        vw |= ((unsigned)(wo + dd) < (unsigned)a.W) ? (1u << r) : 0u;
+      }
+      const uint32_t mask = ((vh & 1u) ? vw : 0u) | ((vh & 2u) ? vw << 3 : 0u) | ((vh & 4u) ? vw << 6 : 0u);
+      fmask[j] = p < P ? mask : 0u;
+      p += 16;
+      wo += 16;
+      while (wo >= a.W) {
+        wo -= a.W;
+        if (++ho >= a.H) ho = 0;
+      }
+    }
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
+  const uint32_t xk0 = (uint32_t)((h ^ (r16 & 7)) << 4);
+  const uint32_t rowA = lds0 + (uint32_t)((wm * 128 + r16) * RSB) + xk0;      // k-step 0; k-step 1 = ^ 0x40 (the rows are 128-byte aligned)
+  const uint32_t ldsP = lds0 + (uint32_t)(2 * ASTAGE);
+  const uint32_t zaddr = ldsP + (uint32_t)(2 * PATCH);
+  const int rowb0 = lead + wn * (NT * 16) + r16;
+
+  // addresses of this lane's NT pixel-tile fragments (k-step 0) for tap (t, tr, ts) of chunk c: the patch row of the neighbour, or
+  // the zero row where the image has none — zx + (valid ? patch address - zx : 0) with the validity bit spread to a mask by one
+  // signed bit-field extract: four VALU per fragment, no VCC round trip.  The empty asm statements pin each half to the MFMA gap
+  // it is written in (otherwise the compiler sinks all of it to the first use, into one gap).
+  uint32_t addrB[NT];
+  const int dsgn = fwd ? 1 : -1;
+  uint32_t nb_zx = 0;
+  int nb_d0 = 0, nb_t = 0, nb_m = 0;
+  int nb_ds = 0, nb_ps = 0;                                  // scalar halves of the next tap's common terms
+  auto tap_common_s = [&](int tr, int ts, int c) {
+    nb_ds = dsgn * ((tr - 1) * a.W + (ts - 1));             // forward: the neighbour (r - 1, s - 1); input gradient: (1 - r, 1 - s)
+    nb_ps = (int)ldsP + (c & 1) * PATCH - (int)zaddr;
+    asm volatile("" : "+s"(nb_ds), "+s"(nb_ps));
+  };
+  auto tap_common_v = [&](int t) {
+    const int rowb = rowb0 + nb_ds;
+    const uint32_t xb0 = ((uint32_t)h ^ (uint32_t)(rowb & 7)) << 4;
+    nb_zx = zaddr + xb0;
+    nb_d0 = nb_ps + rowb * RSB;
+    nb_t = t;
+    asm volatile("" : "+v"(nb_zx), "+v"(nb_d0));
+  };
+  auto tap_common = [&](int t, int tr, int ts, int c) {
+    tap_common_s(tr, ts, c);
+    tap_common_v(t);
+  };
+  auto tap_addr_a = [&](int j) {
+    nb_m = __builtin_amdgcn_sbfe((int)fmask[j], nb_t, 1) & (nb_d0 + j * 16 * RSB);
+    asm volatile("" : "+v"(nb_m));
+  };
+  auto tap_addr_b = [&](int j) {
+    addrB[j] = nb_zx + (uint32_t)nb_m;
+    asm volatile("" : "+v"(addrB[j]));
+  };
+  tap_common(0, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    tap_addr_a(j);
+    tap_addr_b(j);
+  }
+
+  bf16x8 F[2][MT + NT];      // [buffer][8 weight fragments | NT pixel fragments] of one k-step
+  auto read_a = [&](auto buf_tag, auto i_tag, uint32_t addr) {
+    constexpr int B = decltype(buf_tag)::value, I = decltype(i_tag)::value;
+    F[B][I] = lds_read128_asm<I * 16 * RSB>(addr);
+  };
+  auto read_b = [&](auto buf_tag, auto j_tag, uint32_t addr) {
+    constexpr int B = decltype(buf_tag)::value, J = decltype(j_tag)::value;
+    F[B][MT + J] = lds_read128_asm<0>(addr);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: k-tile 0 and patch 0 complete; fragments of step 0
+  // (k-tile 1's weight pieces, issued last, stay in flight: the loop's first barrier drains them; lgkmcnt: the zero row's ds_write)
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PA) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  static_for<MT>([&](auto ic) { read_a(B0{}, ic, rowA); });
+  static_for<NT>([&](auto jc) { read_b(B0{}, jc, addrB[decltype(jc)::value]); });
+
+  const bool dma = !(a.dbg & 32);                       // diagnostic: no DMA after the prologue
+  const bool tr_on = TRACE && a.trace && bx == 7 && by == 0 && wave == 0;
+  if constexpr (TRACE) {
+    if (tr_on && lane == 0) __builtin_nontemporal_store((long long)__builtin_amdgcn_s_memrealtime(), a.trace + 128);
+  }
+  // Loop-carried scalars, advanced INSIDE the MFMA gaps (a wave alone on its SIMD issues in order: thirty scalar instructions at the
+  // loop head are thirty instructions during which the matrix pipe has nothing queued; the empty asm statements pin a value to the
+  // gap it is computed in): tap / chunk of this k-tile (t, c) and of the next (tn, trn, tsn, cn), this k-tile's weight buffer (sb);
+  // for the second step: byte offset of weight piece 0 of k-tile u + 2 (k2s), its per-lane offset (a_voff: out of range when there is
+  // no such tile), destination and byte offset of this tap's piece(s) of the next patch.
+  int t = 0, c = 0, tn = 1, trn = 0, tsn = 1, cn = 0;
+  uint32_t sb = 0;
+  int k2s = 0, a_voff = OOB;
+  uint32_t p_dst[PPW];
+  int p_soff[PPW];
+  int s_tmp0 = 0, s_tmp1 = 0, s_px = 0, s_due = 0;
+  const uint32_t dump = (uint32_t)(uintptr_t)(lds_void_t*)(sP + 2 * PATCH + 128);
+  for (int u = 0; u < nk; ++u) {
+    // ---- step 2u (k = 0..31 of this tap, fragments F[0]); reads of step 2u + 1 into F[1], then the next tap's addresses
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (TRACE) {
+      if (tr_on && u < 64) {
+        const long long c_ = (long long)__builtin_readcyclecounter();
+        if (lane == 0) __builtin_nontemporal_store(c_, a.trace + u * 2);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NMF>([&](auto nc) {
+      constexpr int n = decltype(nc)::value, i = n / NT, j = n % NT;
+      constexpr int G = MT + NT;            // first gap behind the fragment reads
+      mfma16_agpr(acc[i][j], F[0][i], F[0][MT + j]);
+      if constexpr (n < MT) read_a(B1{}, std::integral_constant<int, n>{}, (rowA + sb) ^ 0x40u);
+      else if constexpr (n < G) read_b(B1{}, std::integral_constant<int, n - MT>{}, addrB[n - MT] ^ 0x40u);
+      else if constexpr (n == G) tap_common_s(trn, tsn, cn);
+      else if constexpr (n == G + 1) tap_common_v(tn);
+      else if constexpr (n >= G + 2 && n < G + 2 + 2 * NT) {
+        if constexpr (((n - (G + 2)) & 1) == 0) tap_addr_a((n - (G + 2)) >> 1);
+        else tap_addr_b((n - (G + 2)) >> 1);
+      } else if constexpr (n == G + 2 + 2 * NT) {          // weight tile of k-tile u + 2: tap t + 2 of this chunk, or tap t - 7 of the next
+        const int wrap = t + 2 >= 9;
+        s_tmp0 = (wrap ? t - 7 : t + 2) * a.C;
+        s_tmp1 = (c + wrap) * BK;
+        asm volatile("" : "+s"(s_tmp0), "+s"(s_tmp1));
+      } else if constexpr (n == G + 3 + 2 * NT) {
+        k2s = (s_tmp0 + s_tmp1) * 2;
+        a_voff = ((int)(u + 2 < nk) & (int)dma) ? a_off0 : OOB;
+        asm volatile("" : "+s"(k2s), "+v"(a_voff));
+      } else if constexpr (n >= G + 4 + 2 * NT && n < G + 4 + 2 * NT + 3 * PPW) {   // this tap's piece(s) of the next chunk's patch, three gaps each
+        constexpr int e = (n - (G + 4 + 2 * NT)) / 3, part = (n - (G + 4 + 2 * NT)) % 3;
+        if constexpr (part == 0) {
+          s_px = (t * NW + wave) * PPW + e;
+          s_due = -((int)dma & (int)(t < 8) & (int)(c + 1 < nchunk) & (int)(s_px < NPI));      // all ones / zero (no branch)
+          asm volatile("" : "+s"(s_px), "+s"(s_due));
+        } else if constexpr (part == 1) {
+          p_dst[e] = dump + ((ldsP + (uint32_t)(((c + 1) & 1) * PATCH + s_px * 1024) - dump) & (uint32_t)s_due);
+          asm volatile("" : "+s"(p_dst[e]));
+        } else {
+          p_soff[e] = s_px * 8 * rowbytes + (c + 1) * (BK * 2);
+          asm volatile("" : "+s"(p_soff[e]));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- step 2u + 1 (k = 32..63, fragments F[1]); the k-tile's barrier; DMA of k-tile u + 2 and of the patch piece; reads of step 2u + 2
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TRACE) {
+      if (tr_on && u < 64) {
+        const long long c_ = (long long)__builtin_readcyclecounter();
+        if (lane == 0) __builtin_nontemporal_store(c_, a.trace + u * 2 + 1);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NMF>([&](auto nc) {
+      constexpr int n = decltype(nc)::value, i = n / NT, j = n % NT;
+      mfma16_agpr(acc[i][j], F[1][i], F[1][MT + j]);
+      // gap n: every DSTEP-th gap issues one LDS-DMA piece (weight pieces first, then the patch piece: spread over the step so that
+      // the four waves do not queue 36 pieces on the CU's one address path right behind the barrier), the gaps between them the 15
+      // fragment reads of step 2u + 2, then the scalars of the next k-tile
+      constexpr int ND = PA + PPW;
+      constexpr bool isdma = n % DSTEP == 0 && n / DSTEP < ND;
+      constexpr int ndma_before = (n + DSTEP - 1) / DSTEP < ND ? (n + DSTEP - 1) / DSTEP : ND;   // DMA gaps among 0 .. n - 1
+      constexpr int rd = n - ndma_before;                                                        // index among the non-DMA gaps
+      if constexpr (isdma) {
+        constexpr int e = n / DSTEP;
+        if constexpr (e < PA) {
+          // (no k-tile u + 2: out-of-range offset — no memory traffic, zeros into the buffer nobody reads again)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + sb + (e * NW + wave) * 1024), 16, a_voff,
+                                                   k2s + e * a_estep, 0, 0);
+        } else {
+          // rows in front of the tensor or behind it: the offset itself is out of the descriptor's range (negative pq_off wraps)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(uintptr_t)p_dst[e - PA], 16, pq_off + p_soff[e - PA], 0, 0, 0);
+        }
+      } else if constexpr (rd < MT) {
+        read_a(B0{}, std::integral_constant<int, rd>{}, rowA + (sb ^ (uint32_t)ASTAGE));
+      } else if constexpr (rd < MT + NT) {
+        read_b(B0{}, std::integral_constant<int, rd - MT>{}, addrB[rd - MT]);
+      }
+      // behind the last LDS-DMA gap (its destination is this k-tile's buffer sb): the next k-tile becomes this one
+      constexpr int ADV = (ND - 1) * DSTEP + 1 > ND + MT + NT ? (ND - 1) * DSTEP + 1 : ND + MT + NT;
+      if constexpr (n == ADV) {
+        t = tn;
+        c = cn;
+        sb ^= (uint32_t)ASTAGE;
+        asm volatile("" : "+s"(t), "+s"(c), "+s"(sb));
+      } else if constexpr (n == ADV + 1) {
+        ++tn;
+        ++tsn;
+        asm volatile("" : "+s"(tn), "+s"(tsn));
+      } else if constexpr (n == ADV + 2) {
+        const int w3 = tsn == 3;
+        tsn = w3 ? 0 : tsn;
+        trn += w3;
+        asm volatile("" : "+s"(tsn), "+s"(trn));
+      } else if constexpr (n == ADV + 3) {
+        const int w9 = tn == 9;
+        cn += w9;
+        tn = w9 ? 0 : tn;
+        asm volatile("" : "+s"(tn), "+s"(cn));
+      } else if constexpr (n == ADV + 4) {
+        const int z = tn == 0;                             // (tap 0 is only ever reached by the wrap)
+        trn = z ? 0 : trn;
+        tsn = z ? 0 : tsn;
+        asm volatile("" : "+s"(tsn), "+s"(trn));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  if constexpr (TRACE) {
+    if (tr_on && lane == 0) __builtin_nontemporal_store((long long)__builtin_amdgcn_s_memrealtime(), a.trace + 129);
+  }
+  // (the last step prefetched fragments nobody uses; the s_nops: the MFMAs are inline asm, so the compiler's hazard recogniser does
+  // not know that the accumulators it is about to read were written by the matrix pipe)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (a.dbg & 64) {                             // diagnostic: no epilogue
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0] + acc[3][NT - 1][3] + acc[1][2][1] + acc[7][5][2];
+    return;
+  }
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, false>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
+  if constexpr (TRACE) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores and atomics of this wave have been acknowledged
+    if (tr_on && lane == 0) __builtin_nontemporal_store((long long)__builtin_amdgcn_s_memrealtime(), a.trace + 131);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv_igemm_halo_kernel -- 3x3 / stride 1 / pad 1 convolutions (forward and input gradient) with the
 // gathered operand kept as ONE halo'd pixel patch per 64-channel chunk instead of nine shifted copies.
 // Written to test whether the per-CU L2->LDS volume (32 KB per 128x128x64 k-tile) bounds the LDS-DMA kernel
@@ -1956,6 +2582,48 @@ int launch_igemm_p8(const ConvArgs& a, int P, hipStream_t st) {
   return VLSFR_OK;
 }
 
+// LDS of conv_igemm_hp8_kernel: two weight buffers, two patches, the zero row.  lead = halo rows in front of the tile's first pixel
+inline int hp8_lead(int BN, int W) { return BN % W == 0 ? W : W + 1; }
+inline int hp8_patch_rows(int BN, int W) { return (BN + 2 * hp8_lead(BN, W) + 7) & ~7; }
+inline int hp8_lds_bytes(int BM, int BN, int W) { return 2 * BM * 128 + 2 * hp8_patch_rows(BN, W) * 128 + 128; }
+
+template <int BM, int NT>
+int launch_igemm_hp8(const ConvArgs& a, int P, hipStream_t st) {
+  constexpr int BN = (8 / (BM / 64)) * NT * 16;
+  const int lead = hp8_lead(BN, a.W), PR = hp8_patch_rows(BN, a.W);
+  const int lds = hp8_lds_bytes(BM, BN, a.W);
+  auto kern = a.trace ? conv_igemm_hp8_kernel<BM, NT, 1> : (a.dbg & 256) ? conv_igemm_hp8_kernel<BM, NT, 2> : conv_igemm_hp8_kernel<BM, NT, 0>;
+  if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_hp8")) return rc;
+  dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, 1);
+  ConvArgs b = a;
+  const size_t nwg = (size_t)grid.x * grid.y;
+  b.gx = (int)grid.x;
+  b.gy = (int)grid.y;
+  b.xcd = g_xcd_map && nwg >= 16 && nwg < (1u << 30);
+  if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, b, PR, lead);
+  return VLSFR_OK;
+}
+
+template <int BM, int NT>
+int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st) {
+  constexpr int BN = (4 / (BM / 128)) * NT * 16;
+  const int lead = hp8_lead(BN, a.W), PR = hp8_patch_rows(BN, a.W);
+  const int lds = hp8_lds_bytes(BM, BN, a.W) + 1024;   // + the dump area of the LDS-DMA pieces that have nothing to fetch
+  auto kern = a.trace ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
+                      : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
+  if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_hw4")) return rc;
+  dim3 grid((P + BN - 1) / BN, a.Mrows / BM, 1);
+  ConvArgs b = a;
+  const size_t nwg = (size_t)grid.x * grid.y;
+  b.gx = (int)grid.x;
+  b.gy = (int)grid.y;
+  b.xcd = g_xcd_map && nwg >= 16 && nwg < (1u << 30);
+  if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b, PR, lead);
+  return VLSFR_OK;
+}
+
 template <int BM, int PI>
 int launch_igemm_halo(const ConvArgs& a, int P, hipStream_t st) {
   const int PR = ((128 + 2 * a.W + 2) + 7) & ~7;
@@ -2003,9 +2671,23 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   // the default LDS-DMA variant's per-shape choices (decided here so that the timing bracket knows its family)
   const bool variant_default = g_use_glds == VLSFR_DEFAULT_CONV_VARIANT;
   const bool big_tile = a.Mrows >= 128 && wg_big >= g_small_tile_wgs;
-  const bool tile256_here = glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
+  // the halo-patch four-phase kernel: 3x3 / stride 1, 256-row tiles x 224 pixels or 128-row tiles x 448 pixels, where those tiles
+  // fill at least g_hp8_fill % of the workgroup slots of their rounds (ir100 at batch 256: 224 tiles on the 256-channel 14 x 14
+  // layers, 448 on the 128-channel 28 x 28 layers).  A launch that wants the fused BatchNorm-backward reduction takes the
+  // stand-alone reduction kernel instead (red_done stays false), as with the one-round tiles below.
+  int hp8_bm = 0;
+  if (glds_ok && !halo_ok && variant_default && g_conv_hp8 && !a.tap_mask && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 &&
+      a.splitk == 1 && !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.H >= 2 && !g_bnred_all) {
+    const int bm = (a.Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (a.Mrows == 128 && g_conv_hp8 != 2) ? 128 : 0;
+    if (bm) {
+      const int bn = bm == 256 ? 224 : 448;
+      const long tiles = (long)((P + bn - 1) / bn) * (a.Mrows / bm), rounds = (tiles + 255) / 256;
+      if (hp8_lds_bytes(bm, bn, a.W) + 1024 <= 160 * 1024 && hp8_patch_rows(bn, a.W) <= 512 && tiles * 100 >= rounds * 256 * g_hp8_fill) hp8_bm = bm;
+    }
+  }
+  const bool tile256_here = !hp8_bm && glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
                             P <= 256 * 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
-  const bool red_here = glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
+  const bool red_here = !hp8_bm && glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
                         (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) && (g_bnred_all || (big_tile && !a.cls));
   ProfScope prof(st, red_here ? 3 : 0, alg_flops);
   if (halo_ok) {
@@ -2013,6 +2695,10 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
     const bool pi2 = (128 + 2 * a.W + 2 + 7) / 8 > 32;
     if (a.Mrows >= 128) rc = pi2 ? launch_igemm_halo<128, 2>(a, P, st) : launch_igemm_halo<128, 1>(a, P, st);
     else rc = pi2 ? launch_igemm_halo<64, 2>(a, P, st) : launch_igemm_halo<64, 1>(a, P, st);
+    if (rc != VLSFR_OK) return rc;
+  } else if (hp8_bm) {
+    const int rc = g_conv_hw4 ? (hp8_bm == 256 ? launch_igemm_hw4<256, 7>(a, P, st) : launch_igemm_hw4<128, 7>(a, P, st))
+                              : (hp8_bm == 256 ? launch_igemm_hp8<256, 7>(a, P, st) : launch_igemm_hp8<128, 7>(a, P, st));
     if (rc != VLSFR_OK) return rc;
   } else if (glds_ok) {
     int rc;
@@ -2141,6 +2827,18 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "conv_p8")) {
     g_conv_p8 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_hp8")) {
+    g_conv_hp8 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_hw4")) {
+    g_conv_hw4 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "hp8_fill")) {
+    g_hp8_fill = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "tile256_min")) {
