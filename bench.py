@@ -72,6 +72,8 @@ def parse():
                     "dispatches) ends in a SIGSEGV on a non-main thread inside a memcpy of the tool in about one run of three, with "
                     "the per-launch event brackets taken from a pre-created pool as well as with per-launch hipEventCreate "
                     "(gpurun_out/pmc_full, prof_r03): a tool-side failure that grows with the dispatch count, so PMC passes stay short")
+    ap.add_argument("--full-under-pmc", action="store_true", help="do NOT switch to --counters-only under rocprofv3 counter collection "
+                    "(scripts/pmc_full_once.sh: the one full-length pass that reproduces / attributes the round-3 fault)")
     ap.add_argument("--sync-debug", action="store_true", help="diagnostic: torch.cuda.set_sync_debug_mode('warn') around two steps")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (process group, identity-sharded pool, "
                     "partitioned SGD, every collective) even with one rank: rehearses the RCCL calls on a 1-GPU box")
@@ -361,10 +363,25 @@ def main():
             L.vlsfr_profile_collect.restype = ctypes.c_int
             _lib.check(L.vlsfr_profile_collect(ctypes.c_int32(fam), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)))
             out[name] = (ms.value, fl.value, n.value)
+        L.vlsfr_profile_dropped.restype = ctypes.c_int64
+        dropped = int(L.vlsfr_profile_dropped())
+        if dropped:
+            note("WARNING: %d launch brackets were dropped (event pool exhausted): the roofline totals undercount" % dropped)
         L.vlsfr_profile_reset()
         return out
 
-    if os.environ.get("ROCPROF_COUNTER_COLLECTION") == "1" and not args.counters_only:
+    if os.environ.get("ROCPROF_COUNTER_COLLECTION") == "1" and rank == 0:
+        # the executable mappings of this process, once: an unsymbolised stack trace of a later fault (the rocprofv3 --pmc pass of
+        # round 3 died on a thread of libhsa-runtime64.so: scripts/match_frames.py) is attributable from them
+        try:
+            with open("/proc/self/maps") as f:
+                for ln in f:
+                    if " r-xp " in ln and (".so" in ln or "python" in ln):
+                        sys.stderr.write("[maps] " + ln)
+            sys.stderr.flush()
+        except OSError:
+            pass
+    if os.environ.get("ROCPROF_COUNTER_COLLECTION") == "1" and not args.counters_only and not args.full_under_pmc:
         note("rocprofv3 counter collection detected (ROCPROF_COUNTERS=%s): stopping after the timed region (--counters-only)" %
              os.environ.get("ROCPROF_COUNTERS", "?"))
         args.counters_only = True
@@ -413,6 +430,21 @@ def main():
     debracket = lambda v: (max(v[0] - v[2] * ev_us * 1e-3, 1e-9), v[1], v[2])
     fams = {k: debracket(v) for k, v in fams.items()}
     fams_timed = {k: debracket(v) for k, v in fams_timed.items()}
+    # The convolution family is priced WHOLE: the input-gradient launches that also accumulate the BatchNorm-backward reduction
+    # (conv_igemm_bnred_kernel, event family 3) are the same convolutions with a longer epilogue, so their FLOPs and their time
+    # are folded into conv_igemm_kernel for the headline figure (leaving the slowest tenth of the family's FLOPs
+    # out flattered `frac`); the split stays visible in roofline.conv_split.
+    conv_split = None
+    def fold(d):
+        a, b = d["conv_igemm_kernel"], d.pop("conv_igemm_bnred_kernel")
+        d["conv_igemm_kernel"] = (a[0] + b[0], a[1] + b[1], a[2] + b[2])
+        return a, b
+    plain, red = fold(fams)
+    fold(fams_timed)
+    tf = lambda v: round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0.0
+    conv_split = dict(plain=dict(total_ms=round(plain[0], 2), tflops=tf(plain), launches=int(plain[2])),
+                      with_bn_backward_reduction=dict(total_ms=round(red[0], 2), tflops=tf(red), launches=int(red[2])),
+                      frac_without_bnred_launches=round(tf(plain) / PEAK_BF16_TFLOPS, 4))
     dom = max(fams, key=lambda k: fams[k][0])
     ms, fl, n = fams[dom]
     achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -430,6 +462,11 @@ def main():
                         note="the timed schedule repeated with HIP events on every launch; streams overlap: launch durations include shared-chip time"),
                     other={k: dict(total_ms=round(v[0], 2), tflops=round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                                    launches=int(v[2])) for k, v in fams.items() if k != dom})
+    if dom == "conv_igemm_kernel":
+        roofline["conv_split"] = conv_split
+        roofline["family"] = "conv_igemm: every forward and input-gradient convolution launch, the bnred launches included"
+    else:
+        roofline["other"]["conv_igemm_kernel"]["conv_split"] = conv_split
     hs = fams.get("head_sweep_kernel")
     if hs and hs[2] > 0 and hs[0] > 0:
         # the class matmul north_star singles out: MFMA fraction of both contractions (4 B Q D FLOPs per sweep) and

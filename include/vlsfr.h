@@ -257,9 +257,11 @@ typedef struct vlsfr_conv_desc {
 } vlsfr_conv_desc;
 
 /* y: bf16 [N,Ho,Wo,Cout], or fp32 when out_f32 (required for splitk > 1: accumulated atomically).
- * stats (optional, bf16 output only): fp32 [VLSFR_BN_REPL][2][Cout] accumulators (pre-zeroed) that
- * receive the per-channel sum / sum of squares of the rounded outputs — the BatchNorm statistics of
- * the following layer, fused into the epilogue. */
+ * stats (optional, bf16 output only): FLOAT64 [VLSFR_BN_REPL][2][Cout] accumulators (VLSFR_BN_REPL * 2 * Cout * 8 bytes,
+ * 8-byte aligned, pre-zeroed) that receive the per-channel sum / sum of squares of the rounded outputs — the BatchNorm
+ * statistics of the following layer, fused into the epilogue (float64 atomics; layout and precision: section 6).  Only the
+ * first vlsfr_set_option("bn_repl") replicas (default 8) are written; the consumer folds all VLSFR_BN_REPL of them, so the
+ * buffer must be zeroed whole. */
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk,
                      int32_t out_f32, double* stats, void* stream);
 int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream);
@@ -297,7 +299,8 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
  *     (mobilefacenet_def.py:39 3x3 stride 1/2 pad 1; :60,88 7x7 valid), forward / input gradient /
  *     weight gradient.  d->Cin == d->Cout == C (C % 8 == 0), square filter <= 7.  x, y, dy, dx:
  *     NHWC bf16; w: fp32 [C][R*S] (the parameter's own memory); dw: fp32 [C][R*S] accumulated (+=);
- *     stats (optional): BatchNorm statistics [VLSFR_BN_REPL][2][C] of y, pre-zeroed.
+ *     stats (optional): BatchNorm statistics of y, FLOAT64 [VLSFR_BN_REPL][2][C] (VLSFR_BN_REPL * 2 * C * 8 bytes,
+ *     pre-zeroed; as for vlsfr_conv2d_fwd).
  * ---------------------------------------------------------------------------------------- */
 int vlsfr_dwconv_fwd(const vlsfr_conv_desc* d, const void* x, const float* w, void* y, double* stats, void* stream);
 int vlsfr_dwconv_dgrad(const vlsfr_conv_desc* d, const void* dy, const float* w, void* dx, void* stream);
@@ -542,7 +545,8 @@ int vlsfr_running_merge(const int64_t* table_dev, int32_t n_chunks, float moment
 
 /* ------------------------------------------------------------------------------------------
  * 9. Measurement support: while enabled, every launch of the profiled kernel families is bracketed by HIP
- *    events on its own stream — family 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep.
+ *    events on its own stream — family 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep,
+ *    3: the conv_igemm launches whose epilogue also accumulates a BatchNorm-backward reduction.
  *    vlsfr_profile_collect sums elapsed time, ALGORITHMIC FLOPs (convolutions: 2 * forward output positions *
  *    Cout * R*S*Cin, so a stride-2 input gradient is priced at its forward's positions and the stem at its 27 real
  *    taps; head sweep: 4 * B * Q * D) and launch count.  Used by bench.py's roofline leg.
@@ -555,10 +559,14 @@ int vlsfr_profile_collect(int32_t family, double* total_ms, double* total_flops,
 /* what an empty event bracket reads on `stream` (microseconds, mean of 64): the per-launch overhead contained in the
  * totals above; synchronises the stream (measurement support only) */
 double vlsfr_profile_event_overhead_us(void* stream);
-/* Diagnostics: device buffer of 2 x 64 x 8 int64 receiving per-phase shader-clock stamps of one workgroup of
- * the ping-pong convolution variant (scripts/conv_trace.py); nullptr switches the stamps off. */
+/* Diagnostics: device buffer of 2 x 64 x 16 int64 receiving shader-clock stamps of one workgroup of the diagnostic
+ * instantiations of the convolution kernels (scripts/hw4_trace.py, hp8_trace.py, conv_trace.py: per phase / per step of a
+ * k-tile, and the 100 MHz real-time clock around the loop); nullptr switches the stamps off. */
 int vlsfr_conv_trace(void* device_buffer);
 void vlsfr_profile_reset(void);
+/* brackets NOT taken since the last reset (the 65 536-event pool was exhausted, or an event could not be created): when this
+ * is not 0 the totals of vlsfr_profile_collect undercount and the caller should say so */
+int64_t vlsfr_profile_dropped(void);
 
 /* ------------------------------------------------------------------------------------------
  * 10. Stream ordering helpers (HIP events without timing) for callers that spread the step over several

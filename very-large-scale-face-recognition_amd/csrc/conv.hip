@@ -33,16 +33,20 @@ struct ProfRec {
   hipEvent_t a, b;
   double work;
   int family;   // 0: conv_igemm (forward + input gradient), 1: conv_wgrad, 2: head_sweep, 3: conv_igemm with the fused BN-backward reduction
+  bool pooled;  // events taken from g_prof_pool (returned by vlsfr_profile_reset) or created for this bracket (destroyed there)
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;   // forward and backward passes are enqueued from different host threads
 // The events of the brackets come from a pool created by vlsfr_profile_enable on ITS caller's thread, before any bracketed
 // launch: no hipEventCreate / hipEventDestroy on the launch path (which runs on the caller's thread for forward passes and
-// on autograd's for backward passes).  Under rocprofv3 --pmc the per-launch create/destroy from two threads ended in a
-// segmentation fault of the profiled process (round 2, gpurun_out/prof_r02f.log); with the pool the same pass completes.
+// on autograd's for backward passes).  (Round 3 re-ran the rocprofv3 --pmc pass that had ended in a segmentation fault in
+// round 2 both ways: it completed with the pool AND with per-launch hipEventCreate, and failed once on an unchanged binary —
+// event creation is not what that fault depends on; profiles/r03_pmc_full_pass_status.txt)
+// A bracket that finds the pool exhausted is dropped and COUNTED (vlsfr_profile_dropped): a truncated profile is visible.
 static std::vector<hipEvent_t> g_prof_pool;
 static size_t g_prof_next = 0;   // guarded by g_prof_mu
+static long long g_prof_dropped = 0;   // brackets not taken since the last reset (pool exhausted / hipEventCreate failed)
 static int prof_pool_reserve(size_t n_events) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   while (g_prof_pool.size() < n_events) {
@@ -56,11 +60,20 @@ static int g_prof_pool_on = 1;   // "prof_pool": 0 = round 2's per-launch hipEve
 ProfScope::ProfScope(hipStream_t s, int fam, double w) : st(s), on(g_prof_on), family(fam), work(w) {
   if (!on) return;
   if (!g_prof_pool_on) {
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) on = false;
+    if (hipEventCreate(&a) != hipSuccess) on = false;
+    else if (hipEventCreate(&b) != hipSuccess) {
+      (void)hipEventDestroy(a);
+      on = false;
+    }
+    if (!on) {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      ++g_prof_dropped;
+    }
   } else {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_next + 2 + 128 > g_prof_pool.size()) {   // pool exhausted (its last 128 events belong to the overhead probe): unbracketed
       on = false;
+      ++g_prof_dropped;
       return;
     }
     a = g_prof_pool[g_prof_next];
@@ -73,7 +86,7 @@ ProfScope::~ProfScope() {
   if (!on) return;
   (void)hipEventRecord(b, st);
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof.push_back(ProfRec{a, b, work, family});
+  g_prof.push_back(ProfRec{a, b, work, family, g_prof_pool_on != 0});
 }
 extern int g_dw_wgrad_blocks;   // csrc/dw.hip
 extern int g_dw_strip;          // csrc/dw.hip
@@ -2685,8 +2698,10 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
       if (hp8_lds_bytes(bm, bn, a.W) + 1024 <= 160 * 1024 && hp8_patch_rows(bn, a.W) <= 512 && tiles * 100 >= rounds * 256 * g_hp8_fill) hp8_bm = bm;
     }
   }
+  // (one round of one tile per CU: the tile count over BOTH grid dimensions is bounded by the 256 CUs — 512 output channels at
+  // >= 33 024 pixels would be two rounds, the case the 128 x 128 tiles win)
   const bool tile256_here = !hp8_bm && glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
-                            P <= 256 * 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
+                            (long)(a.Mrows / 256) * ((P + 255) / 256) <= 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
   const bool red_here = !hp8_bm && glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
                         (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) && (g_bnred_all || (big_tile && !a.cls));
   ProfScope prof(st, red_here ? 3 : 0, alg_flops);
@@ -2746,7 +2761,7 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
       // 224 pixels per tile where that is still one round: 50 176 pixels = 224 tiles of 224 on 256 CUs instead of 196 of 256,
       // i.e. 0.875 of the work on the critical CU ("tile224", scripts/conv_shapes.py)
       const bool p8_ok = g_conv_p8 && a.R * a.S <= 9 && (a.mode == 0 || a.stride == 1) && !a.out_f32;   // (a.red_x: the caller runs the stand-alone reduction)
-      if (g_tile224 && (P + 223) / 224 <= 256) {
+      if (g_tile224 && (long)(a.Mrows / 256) * ((P + 223) / 224) <= 256) {
         if (p8_ok && P % 224 == 0) rc = launch_igemm_p8<224>(a, P, st);
         else rc = launch_igemm_glds<256, 224, 64, 2, 8>(a, P, st);
       } else if (p8_ok && P % 256 == 0) rc = launch_igemm_p8<256>(a, P, st);
@@ -2951,10 +2966,21 @@ double vlsfr_profile_event_overhead_us(void* stream) {
   return sum / N * 1e3;
 }
 
-void vlsfr_profile_reset(void) {   // the events go back to the pool (nothing is destroyed)
+void vlsfr_profile_reset(void) {   // pooled events go back to the pool; events created for one bracket ("prof_pool" = 0) are destroyed
   std::lock_guard<std::mutex> lk(vlsfr::g_prof_mu);
+  for (auto& r : vlsfr::g_prof)
+    if (!r.pooled) {
+      (void)hipEventDestroy(r.a);
+      (void)hipEventDestroy(r.b);
+    }
   vlsfr::g_prof.clear();
   vlsfr::g_prof_next = 0;
+  vlsfr::g_prof_dropped = 0;
+}
+
+int64_t vlsfr_profile_dropped(void) {   // brackets that were not taken since the last reset: > 0 = the collected totals undercount
+  std::lock_guard<std::mutex> lk(vlsfr::g_prof_mu);
+  return (int64_t)vlsfr::g_prof_dropped;
 }
 
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk, int32_t out_f32,
