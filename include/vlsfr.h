@@ -293,6 +293,16 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
 size_t vlsfr_conv2d_wgrad_workspace_bytes(const vlsfr_conv_desc* d, int32_t splitk);
 int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* n (1 .. 4) weight gradients of the SAME descriptor in one launch — consecutive layers of a stage (the 58 stride-1
+ * 256 -> 256 convolutions of iResNet100 share one shape, model/resnet_arcface.py:36,39): dw[g] += wgrad(dy[g], x[g]).  The
+ * launch splits every problem into n times fewer, longer pixel slices than it would take alone, so the fp32 atomics into
+ * each gradient and the launch / prologue are paid once per n layers' worth of work (84 -> ~65 us per layer at batch 256).
+ * Nothing downstream of a weight gradient runs before the optimizer step, so an executor may defer the weight gradient of a
+ * layer until it has n of them (the dy and x tensors must stay intact until this call is enqueued).  workspace: as for
+ * vlsfr_conv2d_wgrad_ws, vlsfr_conv2d_wgrad_group_workspace_bytes(d, n, splitk) bytes (slab path) or NULL. */
+size_t vlsfr_conv2d_wgrad_group_workspace_bytes(const vlsfr_conv_desc* d, int32_t n, int32_t splitk);
+int vlsfr_conv2d_wgrad_group(const vlsfr_conv_desc* d, int32_t n, const void* const* dy, const void* const* x, float* const* dw,
+                             int32_t splitk, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * 5b. Depthwise convolutions (device).  Replaces nn.Conv2d(groups = C) of MobileFaceNet

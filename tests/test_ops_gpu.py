@@ -582,6 +582,36 @@ def test_wgrad_slab_path_is_deterministic_and_matches_atomics(cin, cout, k, stri
     close(c, (2 * ref).cpu(), 1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,hw,N,n", [(256, 256, 3, 1, 14, 64, 4), (128, 128, 3, 1, 28, 16, 3), (64, 64, 3, 1, 56, 4, 2),
+                                                      (128, 256, 3, 2, 28, 8, 2), (64, 128, 1, 2, 56, 4, 4)])
+def test_wgrad_group_equals_the_single_launches(cin, cout, k, stride, hw, N, n):
+    """vlsfr_conv2d_wgrad_group: n weight gradients of one descriptor in one launch (fewer, longer pixel slices per problem) equal
+    the n single launches up to the order of the fp32 atomics, accumulate into a non-zero dw, and are bit-reproducible on the slab
+    path (wgrad_slabs = 1)."""
+    import ctypes
+    from vlsfr_amd import ops, _lib
+    pad = k // 2
+    ho = ops.out_hw(hw, k, stride, pad)
+    d = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad)
+    gen = torch.Generator(device="cuda").manual_seed(5 + cin + hw)
+    xs = [torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16) for _ in range(n)]
+    dys = [torch.randn(N, ho, ho, cout, device="cuda", generator=gen).to(torch.bfloat16) for _ in range(n)]
+    single = [ops.conv2d_wgrad(dy, x, d) for dy, x in zip(dys, xs)]
+    base = [torch.randn(cout, k, k, cin, device="cuda", generator=gen) for _ in range(n)]
+    got = ops.conv2d_wgrad_group(dys, xs, d, dws=[b.clone() for b in base])
+    for g, s1, b in zip(got, single, base):
+        close(g - b, s1.cpu(), 1e-3)
+    _lib.lib().vlsfr_set_option(b"wgrad_slabs", ctypes.c_int32(1))
+    try:
+        a = ops.conv2d_wgrad_group(dys, xs, d, slabs=True)
+        b2 = ops.conv2d_wgrad_group(dys, xs, d, slabs=True)
+    finally:
+        _lib.lib().vlsfr_set_option(b"wgrad_slabs", ctypes.c_int32(0))
+    for u, v, s1 in zip(a, b2, single):
+        assert torch.equal(u, v)
+        close(u, s1.cpu(), 1e-3)
+
+
 # (cin, cout, stride, hw, N, prelu): conv1 -> bn1 (plain) and conv2 -> bn2 + PReLU of an IBasicBlock backward, on the 128 x 128
 # and the 64 x 128 tile, stride 2 (four parity-class launches accumulate into one reduction), a pixel count that is not a
 # multiple of the tile (ragged last tile), and the 1 x 1 stride-2 shortcut (the rows the launch does not visit are zero)
@@ -650,6 +680,26 @@ def _check_bnred(cin, cout, k, stride, hw, N, prelu):
     scale = np.abs(exact).max(axis=1, keepdims=True) + 1e-12
     np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)
     np.testing.assert_allclose(got / scale, exact / scale, atol=2e-4)
+
+
+@pytest.mark.parametrize("cin,cout,hw,N,prelu", [(256, 256, 14, 37, True), (256, 256, 14, 32, False), (128, 128, 28, 9, True),
+                                                 (128, 128, 28, 16, False), (256, 128, 12, 30, True), (512, 256, 14, 16, True)],
+                         ids=["256ch-ragged-prelu", "256ch-exact", "128ch-ragged-prelu", "128ch-exact", "128ch-unaligned", "256-rows-of-512-cout"])
+def test_dgrad_bnred_in_the_one_wave_per_simd_kernel(cin, cout, hw, N, prelu):
+    """conv_igemm_hw4_kernel<..., RED>: the x tile of the BatchNorm-backward reduction is fetched by LDS-DMA behind the loop and
+    lands under the output stores; dx stays the plain input gradient bit for bit, the three sums match the stand-alone kernel."""
+    import ctypes
+    from vlsfr_amd import _lib
+    torch.manual_seed(cin + cout + hw + N)
+    setopt = lambda name, v: _lib.lib().vlsfr_set_option(name, ctypes.c_int32(v))
+    setopt(b"hp8_fill", 0)
+    try:
+        _check_bnred(cin, cout, 3, 1, hw, N, prelu)
+        setopt(b"hw4_red", 0)                 # and with the stand-alone kernel behind the same convolution kernel
+        _check_bnred(cin, cout, 3, 1, hw, N, prelu)
+    finally:
+        setopt(b"hw4_red", 1)
+        setopt(b"hp8_fill", 80)
 
 
 def test_dgrad_bnred_1x1_stride2_shortcut():

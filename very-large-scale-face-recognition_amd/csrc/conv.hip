@@ -92,6 +92,7 @@ extern int g_dw_wgrad_blocks;   // csrc/dw.hip
 extern int g_dw_strip;          // csrc/dw.hip
 extern int g_bn_chain;          // csrc/iresnet.cpp
 extern int g_dgrad_bnred;       // csrc/iresnet.cpp
+extern int g_wgrad_group;       // csrc/iresnet.cpp
 extern int g_bn_repl;           // csrc/norm.hip
 int head_set_option(const char* name, int32_t value);   // csrc/head.hip: 0 handled, < 0 error, 1 not a head option
 }
@@ -120,6 +121,7 @@ int g_conv_p8 = 1;           // "conv_p8": the four-phases-per-k-tile schedule (
 int g_conv_hp8 = 1;          // "conv_hp8": the halo-patch four-phase kernel (conv_igemm_hp8_kernel) on the 3x3 / stride-1 layers whose tiles fill the chip:
                              // 1 = 256-row and 128-row tiles (default), 2 = 256-row tiles only, 3 = 128-row tiles only, 0 = off
 int g_conv_hw4 = 1;          // "conv_hw4": the one-wave-per-SIMD software-pipelined form of that kernel (conv_igemm_hw4_kernel) where conv_hp8 applies
+int g_hw4_red = 1;           // "hw4_red": conv_igemm_hw4_kernel accumulates the BatchNorm-backward reduction in its epilogue when asked to (0: stand-alone kernel)
 int g_hp8_fill = 80;         // "hp8_fill": least percentage of the workgroup slots of its rounds (256 per round) that conv_igemm_hp8_kernel must fill
 int g_tile256_min = 129;     // "tile256_min": the one-round 8-wave tiles are taken from 256 * this many pixels on, i.e. as soon as the 128 x 128 tiling
                              // (2 cout tiles x P / 128) no longer fits the 512 resident slots: batch 192, 37 632 pixels: 60.7 vs 68.9 us; batch 160
@@ -187,7 +189,7 @@ __device__ __forceinline__ int swz(int row) {
   else return row & 7;
 }
 
-template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED = false>
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED = false, bool XWAIT = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
                                               int r16, int h, int tid, float* red_lds, const char* x_lds = nullptr);
 
@@ -365,7 +367,9 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
 // Shared epilogue of the LDS-DMA convolution kernels: lane (r16, h) of wave (wm, wn) holds channels
 // m0 + wm*(BM/WM) + 16 i + 4h + e of pixels p0 + wn*(BN/WN) + 16 j + r16.  fp32 output (plain or split-K
 // atomics) or bf16 output with the fused BatchNorm statistics; red_lds = BM*WN*2 floats of LDS nobody reads.
-template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED>
+// XWAIT (with RED): the caller issued the LDS-DMA of the x tile right before this call instead of under its last k-tile; the
+// output stores above go first and the reduction waits for the tile (and a workgroup barrier) itself.
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED, bool XWAIT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
                                               int r16, int h, int tid, float* red_lds, const char* x_lds) {
   // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
@@ -580,6 +584,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     // dz = dy * prelu'(z), z = bn(x) = x * zs + zo; sums of dz, dz * (x - mean) (times invstd = dz * xhat) and, for the
     // PReLU slope gradient, dy * z over z <= 0 — from the ROUNDED dy (what the BatchNorm backward reads back)
     constexpr int XCPR = BM / 8;          // 16-byte chunks per x row
+    if constexpr (XWAIT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the x tile (and, older or younger, its output stores)
+      __syncthreads();
+    }
     const uint32_t x_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)x_lds;
     const bool prelu = a.red_slope != nullptr;
     float keep[3][NR];
@@ -1581,7 +1589,10 @@ __device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
 // ------------------------------------------------------------------------------------------------
 // DIAG = 1 (diagnostic instantiation, vlsfr_conv_trace): wave 0 of one workgroup stamps the shader clock at the head of both steps of
 // every k-tile ([64][2]) and the 100 MHz real-time clock around the loop ([128], [129]): cycles per step and the clock the chip holds.
-template <int BM, int NT, int PPW, int DIAG = 0>
+// RED: an input-gradient launch that also accumulates the reduction of the BatchNorm backward reading its output (ConvArgs::red_x,
+// conv_epilogue): the [BN pixels][BM channels] tile of that layer's input is fetched by LDS-DMA into the (now free) LDS as soon as
+// the loop ends and lands under the output stores.
+template <int BM, int NT, int PPW, int DIAG = 0, bool RED = false>
 __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int PR, int lead) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool TRACE = DIAG == 1;
@@ -1895,7 +1906,22 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
     if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0] + acc[3][NT - 1][3] + acc[1][2][1] + acc[7][5][2];
     return;
   }
-  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, false>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
+  if constexpr (RED) {
+    static_assert(BN * BM * 2 <= 2 * BM * 128 + 2 * BN * 128, "the x tile fits the LDS this kernel always has (two weight buffers, two patches of >= BN rows)");
+    constexpr int XRB = BM * 2, XCPR = XRB / 16, XRPI = 1024 / XRB, XI = BN / XRPI / NW;
+    static_assert(BN % (XRPI * NW) == 0, "x tile pieces divide over the waves");
+    const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.red_x, 0, (int)((size_t)P * a.Mrows * 2), 0x00020000);
+    const int rin = lane / XCPR, pc = lane % XCPR;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int r = (wave * XI + i) * XRPI + rin;             // pixel row of the tile
+      const int lc = pc ^ (r & (XCPR - 1));
+      const int q = p0 + r;
+      const int off = q < P ? (q * a.Mrows + m0 + lc * 8) * 2 : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rx, (lds_void_t*)(smem + (wave * XI + i) * 1024), 16, off, 0, 0, 0);
+    }
+  }
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, RED, RED>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
   if constexpr (TRACE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores and atomics of this wave have been acknowledged
     if (tr_on && lane == 0) __builtin_nontemporal_store((long long)__builtin_amdgcn_s_memrealtime(), a.trace + 131);
@@ -2083,6 +2109,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_halo_kernel(ConvArgs a, int
 }
 
 // ------------------------------------------------------------------------------------------------
+#define VLSFR_WGRAD_GROUP_MAX 4
 struct WgradArgs {
   const u16* dy;     // [P, Cout] bf16
   const u16* x;      // [Nimg, H, W, C] bf16 (forward input)
@@ -2096,6 +2123,14 @@ struct WgradArgs {
   float* partial;    // or nullptr: [splitk][Cout][R][S][C] fp32 slabs, slice blockIdx.z written with plain stores and
                      // summed by wgrad_reduce_kernel in a fixed order (deterministic; 1 atomic per element instead of splitk)
   int gx = 0, gy = 0, xcd = 0;   // xcd != 0: 1-D grid of gx * gy * splitk workgroups in XCD-major order, tiles of one pixel slice adjacent
+  // Grouped launch (vlsfr_conv2d_wgrad_group): ngroup weight gradients of the SAME descriptor — consecutive layers of a stage — in
+  // one launch; problem g > 0 takes (dyg, xg, dwg)[g - 1].  The grid's slice dimension is ngroup * splitk: every problem is cut
+  // into ngroup times fewer, longer slices than it would be alone, so the fp32 atomics into its gradient (one 64 KB tile per
+  // workgroup, memory-side) and the launch / prologue are paid once per ngroup layers' worth of work.
+  int ngroup = 1;
+  const u16* dyg[VLSFR_WGRAD_GROUP_MAX - 1] = {};
+  const u16* xg[VLSFR_WGRAD_GROUP_MAX - 1] = {};
+  float* dwg[VLSFR_WGRAD_GROUP_MAX - 1] = {};
 };
 
 template <int BM, int BN, int KT>
@@ -2292,11 +2327,25 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (a.xcd) {   // every tile of one pixel slice reads the same dy / x rows: keep a slice's tiles behind one L2
     const int tiles = a.gx * a.gy;
-    const int g = xcd_major_id(blockIdx.x, tiles * a.splitk);
+    const int g = xcd_major_id(blockIdx.x, tiles * a.splitk * a.ngroup);
     bz = g / tiles;
     const int t = g - bz * tiles;
     by = t / a.gx;
     bx = t - by * a.gx;
+  }
+  // grouped launch: slice index -> (problem, slice of that problem)
+  const u16* dyp = a.dy;
+  const u16* xp = a.x;
+  float* dwp = a.dw;
+  int grp = 0;
+  if (a.ngroup > 1) {
+    grp = bz / a.splitk;
+    bz -= grp * a.splitk;
+    if (grp > 0) {
+      dyp = a.dyg[grp - 1];
+      xp = a.xg[grp - 1];
+      dwp = a.dwg[grp - 1];
+    }
   }
   const int m0 = by * BM;
   const int tap = TPT > 1 ? bx * TPT : bx / a.n_coltiles;          // first tap of the tile
@@ -2310,9 +2359,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
   if (nk <= 0) return;
 
   const __amdgpu_buffer_rsrc_t rs_dy =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)((size_t)P * a.Cout * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)dyp, 0, (int)((size_t)P * a.Cout * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((size_t)a.Nimg * a.H * a.W * a.C * 2), 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, (int)((size_t)a.Nimg * a.H * a.W * a.C * 2), 0x00020000);
 
   // ---- A (dy): lane -> (row in instruction, physical chunk); offset linear in the pixel index
   int a_off[AI];
@@ -2477,7 +2526,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
         }
       }
     __syncthreads();
-    float* slab = a.partial + (size_t)bz * a.Cout * K + (size_t)tap * a.C + c0;
+    float* slab = a.partial + ((size_t)grp * a.splitk + bz) * a.Cout * K + (size_t)tap * a.C + c0;
     constexpr int QPR = BN / 4;   // 16-byte chunks per row
     for (int idx = tid; idx < BM * QPR; idx += 256) {
       const int row = idx / QPR, q = idx - row * QPR;
@@ -2497,7 +2546,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_glds_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int c = c0 + wn * (BN / 2) + j * 16 + r16;
-        if (TPT > 1 || c < a.C) atomicAdd(a.dw + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
+        if (TPT > 1 || c < a.C) atomicAdd(dwp + (size_t)m * K + tap * a.C + c, acc[i][j][e]);
       }
     }
   }
@@ -2525,7 +2574,7 @@ struct WgradPlan {
   int KT, nkt, BM, BN, grid_x, tiles, splitk, n_coltiles;
   bool row3;
 };
-WgradPlan wgrad_plan(const vlsfr_conv_desc* d, int splitk) {
+WgradPlan wgrad_plan(const vlsfr_conv_desc* d, int splitk, int ngroup = 1) {
   WgradPlan w;
   const int Ho = out_dim(d->H, d->R, d->stride, d->pad), Wo = out_dim(d->W, d->S, d->stride, d->pad);
   const int P = d->N * Ho * Wo;
@@ -2540,7 +2589,8 @@ WgradPlan wgrad_plan(const vlsfr_conv_desc* d, int splitk) {
   w.grid_x = w.row3 ? 3 : w.n_coltiles * d->R * d->S;
   w.tiles = w.grid_x * ((d->Cout + w.BM - 1) / w.BM);
   if (splitk <= 0) {   // at most g_wgrad_target workgroups (never a second round: one more slice than fits costs a third), >= 8 k-tiles each
-    splitk = g_wgrad_round_up ? (g_wgrad_target + w.tiles - 1) / w.tiles : g_wgrad_target / w.tiles;
+    // (a grouped launch shares the workgroup budget between its ngroup problems: each gets ngroup times fewer, longer slices)
+    splitk = g_wgrad_round_up ? (g_wgrad_target + w.tiles * ngroup - 1) / (w.tiles * ngroup) : g_wgrad_target / (w.tiles * ngroup);
     if (splitk > w.nkt / 8) splitk = w.nkt / 8;
     if (splitk < 1) splitk = 1;
   }
@@ -2619,12 +2669,13 @@ int launch_igemm_hp8(const ConvArgs& a, int P, hipStream_t st) {
 }
 
 template <int BM, int NT>
-int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st) {
+int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
   constexpr int BN = (4 / (BM / 128)) * NT * 16;
   const int lead = hp8_lead(BN, a.W), PR = hp8_patch_rows(BN, a.W);
   const int lds = hp8_lds_bytes(BM, BN, a.W) + 1024;   // + the dump area of the LDS-DMA pieces that have nothing to fetch
-  auto kern = a.trace ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
-                      : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
+  auto kern = red       ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0, true> : conv_igemm_hw4_kernel<BM, NT, 1, 0, true>)
+              : a.trace ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
+                        : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
   if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_hw4")) return rc;
   dim3 grid((P + BN - 1) / BN, a.Mrows / BM, 1);
   ConvArgs b = a;
@@ -2690,7 +2741,7 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   // stand-alone reduction kernel instead (red_done stays false), as with the one-round tiles below.
   int hp8_bm = 0;
   if (glds_ok && !halo_ok && variant_default && g_conv_hp8 && !a.tap_mask && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 &&
-      a.splitk == 1 && !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.H >= 2 && !g_bnred_all) {
+      a.splitk == 1 && !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.H >= 2 && !(g_bnred_all && !(g_conv_hw4 && g_hw4_red))) {
     const int bm = (a.Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (a.Mrows == 128 && g_conv_hp8 != 2) ? 128 : 0;
     if (bm) {
       const int bn = bm == 256 ? 224 : 448;
@@ -2704,7 +2755,10 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
                             (long)(a.Mrows / 256) * ((P + 255) / 256) <= 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
   const bool red_here = !hp8_bm && glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
                         (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) && (g_bnred_all || (big_tile && !a.cls));
-  ProfScope prof(st, red_here ? 3 : 0, alg_flops);
+  // the one-wave-per-SIMD kernel carries the reduction itself ("hw4_red", default on): x tile fetched behind the loop
+  const bool hw4_red = hp8_bm && g_conv_hw4 && g_hw4_red && a.red_x && !a.cls &&
+                       (size_t)P * a.Mrows < (1ull << 30);
+  ProfScope prof(st, (red_here || hw4_red) ? 3 : 0, alg_flops);
   if (halo_ok) {
     int rc;
     const bool pi2 = (128 + 2 * a.W + 2 + 7) / 8 > 32;
@@ -2712,8 +2766,9 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
     else rc = pi2 ? launch_igemm_halo<64, 2>(a, P, st) : launch_igemm_halo<64, 1>(a, P, st);
     if (rc != VLSFR_OK) return rc;
   } else if (hp8_bm) {
-    const int rc = g_conv_hw4 ? (hp8_bm == 256 ? launch_igemm_hw4<256, 7>(a, P, st) : launch_igemm_hw4<128, 7>(a, P, st))
+    const int rc = g_conv_hw4 ? (hp8_bm == 256 ? launch_igemm_hw4<256, 7>(a, P, st, hw4_red) : launch_igemm_hw4<128, 7>(a, P, st, hw4_red))
                               : (hp8_bm == 256 ? launch_igemm_hp8<256, 7>(a, P, st) : launch_igemm_hp8<128, 7>(a, P, st));
+    if (hw4_red && red_done) *red_done = true;
     if (rc != VLSFR_OK) return rc;
   } else if (glds_ok) {
     int rc;
@@ -2852,6 +2907,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
     g_conv_hw4 = value;
     return VLSFR_OK;
   }
+  if (name && !strcmp(name, "hw4_red")) {
+    g_hw4_red = value;
+    return VLSFR_OK;
+  }
   if (name && !strcmp(name, "hp8_fill")) {
     g_hp8_fill = value;
     return VLSFR_OK;
@@ -2890,6 +2949,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "bn_chain")) {
     vlsfr::g_bn_chain = value != 0;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "wgrad_group")) {
+    vlsfr::g_wgrad_group = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "dgrad_bnred")) {
@@ -3126,13 +3189,24 @@ int vlsfr_conv2d_wgrad(const vlsfr_conv_desc* d, const void* dy, const void* x, 
 
 int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* x, float* dw, int32_t splitk,
                           void* workspace, size_t workspace_bytes, void* stream) {
+  return vlsfr_conv2d_wgrad_group(d, 1, &dy, &x, &dw, splitk, workspace, workspace_bytes, stream);
+}
+
+size_t vlsfr_conv2d_wgrad_group_workspace_bytes(const vlsfr_conv_desc* d, int32_t n, int32_t splitk) {
+  if (conv_check(d, "vlsfr_conv2d_wgrad_group_workspace_bytes") || n < 1 || n > VLSFR_WGRAD_GROUP_MAX) return 0;
+  const WgradPlan w = wgrad_plan(d, splitk, n);
+  return w.splitk > 1 ? (size_t)n * w.splitk * d->Cout * d->R * d->S * d->Cin * sizeof(float) : 0;
+}
+
+int vlsfr_conv2d_wgrad_group(const vlsfr_conv_desc* d, int32_t n, const void* const* dy, const void* const* x, float* const* dw,
+                             int32_t splitk, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = conv_check(d, "vlsfr_conv2d_wgrad");
   if (rc) return rc;
-  if (!dy || !x || !dw) return fail(VLSFR_EINVAL, "vlsfr_conv2d_wgrad: null buffer");
+  if (n < 1 || n > VLSFR_WGRAD_GROUP_MAX || !dy || !x || !dw)
+    return fail(VLSFR_EINVAL, "vlsfr_conv2d_wgrad_group: 1 .. %d problems", VLSFR_WGRAD_GROUP_MAX);
+  for (int g = 0; g < n; ++g)
+    if (!dy[g] || !x[g] || !dw[g]) return fail(VLSFR_EINVAL, "vlsfr_conv2d_wgrad: null buffer");
   WgradArgs a;
-  a.dy = (const u16*)dy;
-  a.x = (const u16*)x;
-  a.dw = dw;
   a.Nimg = d->N;
   a.H = d->H;
   a.W = d->W;
@@ -3145,17 +3219,33 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
   a.stride = d->stride;
   a.pad = d->pad;
   const int P = a.Nimg * a.Ho * a.Wo;
-  const WgradPlan w = wgrad_plan(d, splitk);
+  const bool glds = g_wgrad_glds && d->Cin % 8 == 0 && d->Cout % 8 == 0 && (size_t)P * d->Cout < (1ull << 30) &&
+                    (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30);
+  if (n > 1 && !glds) {   // the register-staged kernel has no grouped form: one launch per problem
+    for (int g = 0; g < n; ++g)
+      if ((rc = vlsfr_conv2d_wgrad_group(d, 1, dy + g, x + g, dw + g, splitk, workspace, workspace_bytes, stream))) return rc;
+    return VLSFR_OK;
+  }
+  a.dy = (const u16*)dy[0];
+  a.x = (const u16*)x[0];
+  a.dw = dw[0];
+  a.ngroup = n;
+  for (int g = 1; g < n; ++g) {
+    a.dyg[g - 1] = (const u16*)dy[g];
+    a.xg[g - 1] = (const u16*)x[g];
+    a.dwg[g - 1] = dw[g];
+  }
+  const WgradPlan w = wgrad_plan(d, splitk, n);
   const int KT = w.KT, BM = w.BM, BN = w.BN, grid_x = w.grid_x;
   splitk = w.splitk;
   a.n_coltiles = w.n_coltiles;
   a.splitk = splitk;
   const size_t n_dw = (size_t)d->Cout * d->R * d->S * d->Cin;
-  const size_t need = (size_t)splitk * n_dw * sizeof(float);
+  const size_t need = (size_t)n * splitk * n_dw * sizeof(float);
   // slab path: enough workspace, more than one slice, 16-byte granularity of the reduction
   a.partial = (workspace && splitk > 1 && workspace_bytes >= need && n_dw % 4 == 0 && g_wgrad_slabs) ? (float*)workspace : nullptr;
   a.dbg = g_conv_dbg;
-  dim3 grid(grid_x, (d->Cout + BM - 1) / BM, splitk);
+  dim3 grid(grid_x, (d->Cout + BM - 1) / BM, splitk * n);
   a.gx = (int)grid.x;
   a.gy = (int)grid.y;
   a.xcd = 0;
@@ -3163,9 +3253,7 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
   // algorithmic FLOPs (the 32-channel 1x1 case is the stem on im2col rows: 27 real taps)
   const double alg_k = (d->R == 1 && d->S == 1 && (d->Cin == 32 || d->Cin == 160)) ? (d->Cin == 32 ? 27.0 : 147.0)
                                                                                    : (double)d->R * d->S * d->Cin;
-  ProfScope prof(st, 1, 2.0 * P * (double)d->Cout * alg_k);
-  const bool glds = g_wgrad_glds && d->Cin % 8 == 0 && d->Cout % 8 == 0 && (size_t)P * d->Cout < (1ull << 30) &&
-                    (size_t)a.Nimg * a.H * a.W * a.C < (1ull << 30);
+  ProfScope prof(st, 1, 2.0 * n * P * (double)d->Cout * alg_k);
   if (glds && g_xcd_map && (size_t)grid.x * grid.y * grid.z >= 16) {
     a.xcd = 1;
     grid = dim3(grid.x * grid.y * grid.z, 1, 1);
@@ -3194,8 +3282,9 @@ int vlsfr_conv2d_wgrad_ws(const vlsfr_conv_desc* d, const void* dy, const void* 
   if (a.partial) {
     const int64_t n4 = (int64_t)n_dw / 4;
     const int64_t blocks = (n4 + 255) / 256;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, a.partial, dw, n4,
-                       (int64_t)n_dw, splitk);
+    for (int g = 0; g < n; ++g)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st,
+                         a.partial + (size_t)g * splitk * n_dw, dw[g], n4, (int64_t)n_dw, splitk);
     VLSFR_HIP_CHECK_LAUNCH("conv_wgrad reduce launch");
   }
   return VLSFR_OK;

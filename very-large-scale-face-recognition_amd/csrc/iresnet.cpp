@@ -19,8 +19,13 @@ int g_bn_chain = 1;   // "bn_chain": bn1 backward of block k accumulates the red
 int g_dgrad_bnred = 1;   // "dgrad_bnred": the reductions of bn2 / bn1 backward come from the epilogue of the input-gradient
                          // convolution that writes their dY (vlsfr_conv2d_dgrad_bnred) instead of a kernel of their own
 }
+namespace vlsfr {
+int g_wgrad_group = 4;   // "wgrad_group": weight gradients of up to this many consecutive same-shape layers in ONE launch
+                         // (vlsfr_conv2d_wgrad_group; 1 = every layer on its own, the round-3 executor)
+}
 using vlsfr::g_bn_chain;
 using vlsfr::g_dgrad_bnred;
+using vlsfr::g_wgrad_group;
 
 namespace {
 
@@ -57,6 +62,8 @@ struct Block {
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr int VLSFR_WGRAD_GROUP = 4;              // the C-ABI's limit of problems per grouped weight-gradient launch
+constexpr int WGRAD_RING = VLSFR_WGRAD_GROUP + 2; // dY buffers: one per waiting weight gradient + the one being written + one of slack
 
 }  // namespace
 
@@ -224,8 +231,10 @@ int build(vlsfr_iresnet* n) {
   n->off_emb = n->take_ctx((size_t)B * n->D * 4);
   n->off_invnorm = n->take_ctx((size_t)B * 4);
   auto ws_of = [&](const Conv& c) {
-    const size_t w = vlsfr_conv2d_wgrad_workspace_bytes(&c.d, 0);
-    if (w > n->wgrad_ws) n->wgrad_ws = w;
+    for (int g = 1; g <= VLSFR_WGRAD_GROUP; ++g) {
+      const size_t w = vlsfr_conv2d_wgrad_group_workspace_bytes(&c.d, g, 0);
+      if (w > n->wgrad_ws) n->wgrad_ws = w;
+    }
   };
   ws_of(n->stem);
   for (auto& b : n->blocks) {
@@ -234,14 +243,16 @@ int build(vlsfr_iresnet* n) {
     if (b.has_ds) ws_of(b.convd);
   }
   ws_of(n->fc);
-  // scratch: 3 activation-sized gradient buffers + the shortcut tensor + small fp32 scratch + the wgrad slabs
-  n->scratch_bytes = 4 * align_up(n->max_act) + align_up((size_t)3 * 2048 * 4) + align_up((size_t)64 * 32 * 4) +
+  // scratch: 3 activation-sized gradient buffers + the shortcut tensor + small fp32 scratch + the wgrad slabs + the ring of
+  // WGRAD_RING activation-sized buffers that hold the dY of weight gradients waiting for their grouped launch
+  n->scratch_bytes = (4 + WGRAD_RING) * align_up(n->max_act) + align_up((size_t)3 * 2048 * 4) + align_up((size_t)64 * 32 * 4) +
                      align_up((size_t)B * n->D * 4) + align_up((size_t)B * n->D * 2) + align_up(n->wgrad_ws);
   return VLSFR_OK;
 }
 
 struct Scratch {
   char* g[3];
+  char* ring[WGRAD_RING];
   char* idn;
   float* red;
   float* stem_dw;
@@ -256,7 +267,8 @@ Scratch carve(const vlsfr_iresnet* n, void* scratch) {
   const size_t a = align_up(n->max_act);
   for (int i = 0; i < 3; ++i) s.g[i] = p + i * a;
   s.idn = p + 3 * a;
-  p += 4 * a;
+  for (int i = 0; i < WGRAD_RING; ++i) s.ring[i] = p + (4 + i) * a;
+  p += (4 + WGRAD_RING) * a;
   s.red = (float*)p;
   p += align_up((size_t)3 * 2048 * 4);
   s.stem_dw = (float*)p;
@@ -274,6 +286,58 @@ Scratch carve(const vlsfr_iresnet* n, void* scratch) {
     int rc__ = (expr);        \
     if (rc__ != VLSFR_OK) return rc__; \
   } while (0)
+
+// Weight gradients waiting for their grouped launch.  Nothing in the backward chain reads a weight gradient, so the executor
+// parks (descriptor, dY, saved input) of a layer here and launches up to g_wgrad_group consecutive layers of one shape together
+// (vlsfr_conv2d_wgrad_group: fewer, longer pixel slices per layer — the fp32 atomics and the launch are shared).  The dY of a
+// waiting entry lives in a ring slot of its own (Scratch::ring) that is not handed out again before the entry has been launched.
+struct WgradQueue {
+  const vlsfr_iresnet* n;
+  float* const* grads;
+  const Scratch* sc;
+  void* st;
+  const Conv* conv[VLSFR_WGRAD_GROUP];
+  const void* dy[VLSFR_WGRAD_GROUP];
+  const void* x[VLSFR_WGRAD_GROUP];
+  int slot[VLSFR_WGRAD_GROUP];
+  int count = 0, next = 0;
+  int flush() {
+    if (!count) return VLSFR_OK;
+    float* dw[VLSFR_WGRAD_GROUP];
+    for (int i = 0; i < count; ++i) dw[i] = grads[conv[i]->p_w];
+    const int rc = vlsfr_conv2d_wgrad_group(&conv[0]->d, count, dy, x, dw, 0, sc->wgrad_ws, n->wgrad_ws, st);
+    count = 0;
+    return rc;
+  }
+  // a ring slot for the dY of the next weight gradient (flushes first if the slot still belongs to a waiting entry)
+  int acquire(char** out) {
+    const int s = next;
+    next = (next + 1) % WGRAD_RING;
+    for (int i = 0; i < count; ++i)
+      if (slot[i] == s) {
+        const int rc = flush();
+        if (rc) return rc;
+        break;
+      }
+    *out = sc->ring[s];
+    cur_slot = s;
+    return VLSFR_OK;
+  }
+  int cur_slot = -1;
+  int push(const Conv& c, const void* dyv, const void* xv) {   // dyv: the slot handed out by the last acquire()
+    const int limit = g_wgrad_group < 1 ? 1 : (g_wgrad_group > VLSFR_WGRAD_GROUP ? VLSFR_WGRAD_GROUP : g_wgrad_group);
+    if (count && (std::memcmp(&conv[0]->d, &c.d, sizeof(vlsfr_conv_desc)) != 0 || count >= limit)) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+    conv[count] = &c;
+    dy[count] = dyv;
+    x[count] = xv;
+    slot[count] = cur_slot;
+    ++count;
+    return count >= limit ? flush() : VLSFR_OK;
+  }
+};
 
 // statistics (already accumulated by the producer of x) -> scale/shift, then y = prelu(bn(x)) + residual
 int bn_forward(const Bn& b, const void* x, void* y, int64_t M, int HW, const void* residual, double* out_sums,
@@ -325,7 +389,7 @@ int forward_block(const vlsfr_iresnet* n, int k, const char* cur, const float* c
 // sc.g[(cur_i + 1) % 3].  `chained`: bn3's reduction came with the kernel that wrote dout; chain_prev: accumulate the
 // reduction of block k - 1's bn3 while writing this block's input gradient (vlsfr_bn_backward_chain).
 int backward_block(const vlsfr_iresnet* n, int k, int cur_i, bool chained, bool chain_prev, const float* const* params,
-                   float* const* grads, char* ctx, const char* wc, const Scratch& sc, void* st) {
+                   float* const* grads, char* ctx, const char* wc, const Scratch& sc, WgradQueue& wq, void* st) {
   const int B = n->B;
   const Block& b = n->blocks[k];
   const char* x_in = k > 0 ? ctx + n->blocks[k - 1].out : ctx + n->off_a0;
@@ -333,25 +397,32 @@ int backward_block(const vlsfr_iresnet* n, int k, int cur_i, bool chained, bool 
   char* t1 = sc.g[(cur_i + 1) % 3];
   char* t2 = sc.g[(cur_i + 2) % 3];
   const char* dout = sc.g[cur_i];
+  // The dY of every convolution goes to a ring slot of its own: its weight gradient is launched later, together with its neighbours'
+  char* r2 = nullptr;
+  char* r1 = nullptr;
   // main branch
-  RUN(bn_backward(b.bn3, dout, ctx + b.c2, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st, chained ? 1 : 0));
-  RUN(vlsfr_conv2d_wgrad_ws(&b.conv2.d, t1, ctx + b.a2, grads[b.conv2.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
+  RUN(wq.acquire(&r2));
+  RUN(bn_backward(b.bn3, dout, ctx + b.c2, r2, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st, chained ? 1 : 0));
+  RUN(wq.push(b.conv2, r2, ctx + b.a2));
   // the input-gradient convolutions accumulate the reductions of the BatchNorm backward that reads their output
   const int fused = g_dgrad_bnred ? 1 : 0;
   auto red_of = [&](const Bn& bn, const void* x) {
     return vlsfr_bn_red{x, (const float*)(ctx + bn.off_mean), (const float*)(ctx + bn.off_invstd), params[bn.p_w], params[bn.p_b],
                         bn.p_slope >= 0 ? params[bn.p_slope] : nullptr, (float*)(ctx + bn.off_red)};
   };
-  const vlsfr_bn_red r2 = red_of(b.bn2, ctx + b.c1), r1 = red_of(b.bn1, x_in);
-  RUN(vlsfr_conv2d_dgrad_bnred(&b.conv2.d, t1, wc + b.conv2.off_wT, t2, fused ? &r2 : nullptr, st));   // d a2
-  RUN(bn_backward(b.bn2, t2, ctx + b.c1, t1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st, fused));   // d c1
-  RUN(vlsfr_conv2d_wgrad_ws(&b.conv1.d, t1, ctx + b.a1, grads[b.conv1.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-  RUN(vlsfr_conv2d_dgrad_bnred(&b.conv1.d, t1, wc + b.conv1.off_wT, t2, fused ? &r1 : nullptr, st));   // d a1 (in t2)
+  const vlsfr_bn_red red2 = red_of(b.bn2, ctx + b.c1), red1 = red_of(b.bn1, x_in);
+  RUN(vlsfr_conv2d_dgrad_bnred(&b.conv2.d, r2, wc + b.conv2.off_wT, t2, fused ? &red2 : nullptr, st));   // d a2
+  RUN(wq.acquire(&r1));
+  RUN(bn_backward(b.bn2, t2, ctx + b.c1, r1, Min, b.H * b.W, nullptr, 0, params, grads, ctx, st, fused));   // d c1
+  RUN(wq.push(b.conv1, r1, ctx + b.a1));
+  RUN(vlsfr_conv2d_dgrad_bnred(&b.conv1.d, r1, wc + b.conv1.off_wT, t2, fused ? &red1 : nullptr, st));   // d a1 (in t2)
   const char* add = dout;
   if (b.has_ds) {   // shortcut branch: d cs, then its weight and input gradients
-    RUN(bn_backward(b.bnd, dout, ctx + b.cs, t1, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
-    RUN(vlsfr_conv2d_wgrad_ws(&b.convd.d, t1, x_in, grads[b.convd.p_w], 0, sc.wgrad_ws, n->wgrad_ws, st));
-    RUN(vlsfr_conv2d_dgrad(&b.convd.d, t1, wc + b.convd.off_wT, sc.idn, st));
+    char* rs = nullptr;
+    RUN(wq.acquire(&rs));
+    RUN(bn_backward(b.bnd, dout, ctx + b.cs, rs, Mout, b.Ho * b.Wo, nullptr, 0, params, grads, ctx, st));
+    RUN(wq.push(b.convd, rs, x_in));
+    RUN(vlsfr_conv2d_dgrad(&b.convd.d, rs, wc + b.convd.off_wT, sc.idn, st));
     add = sc.idn;
   }
   // d x_in = bn1 backward of d a1, plus the shortcut gradient; x_in is the output of block k - 1, so this IS the dY of
@@ -492,17 +563,20 @@ int vlsfr_iresnet_backward_staged(const vlsfr_iresnet* n, const float* demb, con
   int cur_i = 1;
   int stage = 4, left = n->layers[3];   // blocks of the current stage still to go
   bool chained = false;                 // bn3 of the current block already has its reduction
+  WgradQueue wq{n, grads, &sc, st};
   for (int k = (int)n->blocks.size() - 1; k >= 0; --k) {
     const bool chain_prev = g_bn_chain && k > 0;
-    RUN(backward_block(n, k, cur_i, chained, chain_prev, params, grads, ctx, wc, sc, st));
+    RUN(backward_block(n, k, cur_i, chained, chain_prev, params, grads, ctx, wc, sc, wq, st));
     chained = chain_prev;
     cur_i = (cur_i + 1) % 3;   // t1 is the new dcur
     if (--left == 0 && stage > 1) {   // stage 4, 3, 2 complete -> buckets 1, 2, 3 (stage 1 goes with the stem)
+      if (stage_events) RUN(wq.flush());   // somebody waits on the event: the bucket's weight gradients are enqueued in front of it
       RUN(signal(5 - stage));
       --stage;
       left = n->layers[stage - 1];
     }
   }
+  RUN(wq.flush());
   // stem
   char* dc0 = sc.g[(cur_i + 1) % 3];
   RUN(bn_backward(n->stem_bn, sc.g[cur_i], ctx + n->off_c0, dc0, (int64_t)B * S * S, S * S, nullptr, 0, params, grads,
@@ -569,12 +643,14 @@ int vlsfr_iresnet_backward_blocks(const vlsfr_iresnet* n, int32_t k0, int32_t k1
     e = hipMemcpyAsync(sc.g[cur_i], dout, (size_t)n->B * lastb.Ho * lastb.Wo * lastb.planes * 2, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_blocks: %s", hipGetErrorString(e));
   bool chained = false;
+  WgradQueue wq{n, grads, &sc, st};
   for (int k = k1 - 1; k >= k0; --k) {
     const bool chain_prev = g_bn_chain && k > k0;     // inside the range only: block k0 - 1 did not run
-    RUN(backward_block(n, k, cur_i, chained, chain_prev, params, grads, ctx, wc, sc, st));
+    RUN(backward_block(n, k, cur_i, chained, chain_prev, params, grads, ctx, wc, sc, wq, st));
     chained = chain_prev;
     cur_i = (cur_i + 1) % 3;
   }
+  RUN(wq.flush());
   const Block& first = n->blocks[k0];
   e = hipMemcpyAsync(dx, sc.g[cur_i], (size_t)n->B * first.H * first.W * first.cin * 2, hipMemcpyDeviceToDevice, s);
   if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_iresnet_backward_blocks: copy: %s", hipGetErrorString(e));

@@ -205,6 +205,23 @@ def conv2d_wgrad_ws(dy, x, desc, dw=None, splitk=0):
     return dw, n
 
 
+def conv2d_wgrad_group(dys, xs, desc, dws=None, splitk=0, slabs=False):
+    """Weight gradients of len(dys) <= 4 layers of one descriptor in a single launch (vlsfr_conv2d_wgrad_group)."""
+    n = len(dys)
+    if dws is None:
+        dws = [torch.zeros(desc.Cout, desc.R, desc.S, desc.Cin, dtype=torch.float32, device=xs[0].device) for _ in range(n)]
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    L = _lib.lib()
+    ws, nb = None, 0
+    if slabs:
+        L.vlsfr_conv2d_wgrad_group_workspace_bytes.restype = ctypes.c_size_t
+        nb = L.vlsfr_conv2d_wgrad_group_workspace_bytes(ctypes.byref(desc), ctypes.c_int32(n), ctypes.c_int32(splitk))
+        ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=xs[0].device)
+    _call("vlsfr_conv2d_wgrad_group", ctypes.byref(desc), ctypes.c_int32(n), arr(dys), arr(xs), arr(dws), ctypes.c_int32(splitk),
+          _p(ws), ctypes.c_size_t(nb), _st())
+    return dws
+
+
 class BnRed(ctypes.Structure):      # vlsfr_bn_red
     _fields_ = [(n, ctypes.c_void_p) for n in ("x", "mean", "invstd", "gamma", "beta", "slope", "red")]
 
