@@ -264,6 +264,22 @@ typedef struct vlsfr_conv_desc {
  * buffer must be zeroed whole. */
 int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, int32_t splitk,
                      int32_t out_f32, double* stats, void* stream);
+/* Forward convolution whose INPUT is a BatchNorm (+ PReLU) of x, applied inside the kernel's operand path: y = conv(a), a =
+ * prelu(x * scale + shift) (slope NULL: plain BatchNorm), exactly the tensor vlsfr_bn_apply would have written
+ * (model/resnet_arcface.py:45-50: bn1 -> conv1, bn2 -> prelu -> conv2) — without the pass over x that writes it and the pass
+ * that reads it back.  scale / shift: per input channel, from vlsfr_bn_finalize.  a_out (optional): receives a (bf16, shape of
+ * x) as a by-product, for the backward pass (the weight gradient contracts a); NULL in passes that keep no activations.
+ * Supported where vlsfr_conv2d_fwd_bnin_supported(d) != 0 (3x3, stride 1, pad 1, Cin % 64 == 0, Cout 128 or a multiple of 256,
+ * and enough pixels to fill the chip); elsewhere the caller runs vlsfr_bn_apply + vlsfr_conv2d_fwd. */
+typedef struct vlsfr_bn_in {
+  const float* scale;
+  const float* shift;
+  const float* slope;
+  void* a_out;
+} vlsfr_bn_in;
+int32_t vlsfr_conv2d_fwd_bnin_supported(const vlsfr_conv_desc* d);
+int vlsfr_conv2d_fwd_bnin(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, double* stats, const vlsfr_bn_in* bn,
+                          void* stream);
 int vlsfr_conv2d_dgrad(const vlsfr_conv_desc* d, const void* dy, const void* wT, void* dx, void* stream);
 /* The same with the reduction of the BatchNorm (+ PReLU) backward that consumes dx as ITS dY fused into the epilogue
  * (resnet_arcface.py:35-38 backward: bn1 behind conv1, bn2 + prelu behind conv2): x is that layer's input (bf16, shape of
@@ -347,6 +363,12 @@ int vlsfr_bn_stats(const void* x, int64_t M, int32_t C, double* sums, void* stre
  * [n][c][hw] flatten order of the reference's fc input (HW = rows per image); bit 1 applies ReLU AFTER the
  * residual add, y = relu(bn(x) + residual) — the block ending of model/resnet_std.py:97-105 (needs residual,
  * no slope, no out_sums). */
+/* The per-channel part of vlsfr_bn_apply alone: mean / invstd (saved for the backward pass), scale = gamma * invstd, shift =
+ * beta - mean * scale, and the momentum update of running_* (may be NULL) — for a BatchNorm whose element-wise part runs inside
+ * the convolution that consumes it (vlsfr_conv2d_fwd_bnin). */
+int vlsfr_bn_finalize(const double* sums, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                      float* save_mean, float* save_invstd, float* scale, float* shift, float* running_mean, float* running_var,
+                      void* stream);
 int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, const double* sums,
                    const float* gamma, const float* beta, const float* slope, const void* residual,
                    float* save_mean, float* save_invstd, float* running_mean, float* running_var,
@@ -436,6 +458,10 @@ int vlsfr_iresnet_prepare_weights(const vlsfr_iresnet* n, const float* const* pa
 int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params,
                           float* const* running, const void* wcache, void* ctx, void* scratch, float* emb_out,
                           void* stream);
+/* The same; keep_activations == 0: a pass whose activations nobody will read (the gallery network, no_grad): the executor then
+ * skips writing the normalised inputs of the convolutions that apply their BatchNorm themselves (vlsfr_conv2d_fwd_bnin). */
+int vlsfr_iresnet_forward_ex(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params, float* const* running,
+                             const void* wcache, void* ctx, void* scratch, float* emb_out, int32_t keep_activations, void* stream);
 int vlsfr_iresnet_backward(const vlsfr_iresnet* n, const float* demb, const float* const* params,
                            float* const* grads, const void* wcache, void* ctx, void* scratch, void* stream);
 /* The same pass, signalling when groups of parameter gradients are complete, so that a multi-GPU caller can

@@ -582,6 +582,62 @@ def test_wgrad_slab_path_is_deterministic_and_matches_atomics(cin, cout, k, stri
     close(c, (2 * ref).cpu(), 1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,hw,N,prelu", [(256, 256, 14, 256, True), (256, 256, 14, 37, False), (128, 128, 28, 64, True),
+                                                 (128, 128, 28, 9, False), (128, 256, 12, 30, True), (512, 256, 14, 16, True), (64, 128, 28, 7, True)],
+                         ids=["256ch-exact-prelu", "256ch-ragged", "128ch-exact-prelu", "128ch-ragged", "unaligned-prelu", "8-chunks", "1-chunk"])
+def test_conv_with_the_input_batchnorm_in_its_operand_path(cin, cout, hw, N, prelu):
+    """vlsfr_conv2d_fwd_bnin (conv_igemm_hw4_kernel<XF>): y = conv(prelu(bn(x))) with the BatchNorm / PReLU applied to the
+    patch in LDS must equal vlsfr_bn_apply followed by vlsfr_conv2d_fwd — the transformed tensor it writes as a by-product
+    (what the backward pass contracts) and the convolution output with its fused statistics; vlsfr_bn_finalize must give
+    bn_apply's saved mean / invstd and running statistics."""
+    import ctypes
+    from vlsfr_amd import ops, _lib
+    gen = torch.Generator(device="cuda").manual_seed(23 + hw + cin + N)
+    x = (torch.randn(N, hw, hw, cin, device="cuda", generator=gen) * (0.5 + torch.rand(cin, device="cuda", generator=gen)) +
+         torch.randn(cin, device="cuda", generator=gen)).to(torch.bfloat16)
+    w = (torch.randn(cout, 3, 3, cin, device="cuda", generator=gen) * 0.05).contiguous()
+    wb, _ = ops.cast_weight(w, cout, 9, cin)
+    gamma = (1.0 + 0.2 * torch.randn(cin, device="cuda", generator=gen)).contiguous()
+    beta = (0.3 * torch.randn(cin, device="cuda", generator=gen)).contiguous()
+    slope = (0.25 + 0.05 * torch.randn(cin, device="cuda", generator=gen)).contiguous() if prelu else None
+    d = ops.ConvDesc(N, hw, hw, cin, cout, 3, 3, 1, 1)
+    M = N * hw * hw
+    sums = ops.bn_stats(x, M, cin)
+    rm0, rv0 = torch.randn(cin, device="cuda", generator=gen), torch.rand(cin, device="cuda", generator=gen) + 0.5
+    rm_a, rv_a, rm_b, rv_b = rm0.clone(), rv0.clone(), rm0.clone(), rv0.clone()
+    a_ref, mean_ref, invstd_ref = ops.bn_apply(x, M, cin, hw * hw, sums, gamma, beta, slope, running_mean=rm_a, running_var=rv_a)
+    st_ref = ops.new_sums(cout, "cuda")
+    y_ref = ops.conv2d_fwd(a_ref.view(N, hw, hw, cin), wb, d, stats=st_ref)
+    setopt = lambda name, v: _lib.lib().vlsfr_set_option(name, ctypes.c_int32(v))
+    setopt(b"hp8_fill", 0)
+    setopt(b"conv_bnin", 1)               # (off by default: measured slower than bn_apply + conv, DESIGN.md section 8c)
+    try:
+        assert ops.conv2d_fwd_bnin_supported(d)
+        mean, invstd, scale, shift = ops.bn_finalize(sums, M, cin, gamma, beta, running_mean=rm_b, running_var=rv_b)
+        st = ops.new_sums(cout, "cuda")
+        y, a = ops.conv2d_fwd_bnin(x, wb, d, scale, shift, slope, want_a=True, stats=st)
+        y2, none = ops.conv2d_fwd_bnin(x, wb, d, scale, shift, slope, want_a=False)
+        for _ in range(5):        # LDS hand-offs that were wrong would be timing-dependent
+            y3, a3 = ops.conv2d_fwd_bnin(x, wb, d, scale, shift, slope, want_a=True)
+            assert torch.equal(y3, y) and torch.equal(a3, a)
+    finally:
+        setopt(b"hp8_fill", 80)
+        setopt(b"conv_bnin", 0)
+    assert none is None and torch.equal(y2, y)
+    assert torch.equal(mean, mean_ref) and torch.equal(invstd, invstd_ref) and torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b)
+    # the transformed tensor: the same arithmetic as bn_apply; a different instruction selection (fused multiply-add or not) may
+    # move single values by one bf16 step
+    da = (a.float().reshape(-1) - a_ref.float().reshape(-1)).abs()
+    tol = a_ref.float().abs().reshape(-1) * 2.0 ** -7 + 1e-30
+    assert bool((da <= tol).all()), float((da / tol).max())
+    assert float((da > 0).float().mean()) < 1e-3
+    if bool((da == 0).all()):
+        assert torch.equal(y, y_ref)
+    close(y.permute(0, 3, 1, 2), y_ref.float().permute(0, 3, 1, 2).cpu(), 1e-2)
+    close(st.sum(0)[0], st_ref.sum(0)[0].cpu(), 1e-3)
+    close(st.sum(0)[1], st_ref.sum(0)[1].cpu(), 1e-3)
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,hw,N,n", [(256, 256, 3, 1, 14, 64, 4), (128, 128, 3, 1, 28, 16, 3), (64, 64, 3, 1, 56, 4, 2),
                                                       (128, 256, 3, 2, 28, 8, 2), (64, 128, 1, 2, 56, 4, 4)])
 def test_wgrad_group_equals_the_single_launches(cin, cout, k, stride, hw, N, n):

@@ -121,6 +121,11 @@ int g_conv_p8 = 1;           // "conv_p8": the four-phases-per-k-tile schedule (
 int g_conv_hp8 = 1;          // "conv_hp8": the halo-patch four-phase kernel (conv_igemm_hp8_kernel) on the 3x3 / stride-1 layers whose tiles fill the chip:
                              // 1 = 256-row and 128-row tiles (default), 2 = 256-row tiles only, 3 = 128-row tiles only, 0 = off
 int g_conv_hw4 = 1;          // "conv_hw4": the one-wave-per-SIMD software-pipelined form of that kernel (conv_igemm_hw4_kernel) where conv_hp8 applies
+int g_conv_bnin = 0;         // "conv_bnin": vlsfr_conv2d_fwd_bnin (BatchNorm / PReLU of the input applied in conv_igemm_hw4_kernel's operand path) offered to the
+                             // executors.  OFF by default — measured (scripts/bnin_micro.py, batch 256): bn_apply + conv 72.5 us against 73.0 (no a_out) /
+                             // 83.2 us (a_out written) fused on the 256-channel layers, 85.0 against 91.0 / 101.0 on the 128-channel ones; the step
+                             // 87.0 against 83.5 ms: with ONE wave per SIMD the transform's ~200 extra instructions per k-tile sit in the MFMA wave's own
+                             // issue slots, and bn_apply was half hidden beside the other stream's convolutions anyway
 int g_hw4_red = 1;           // "hw4_red": conv_igemm_hw4_kernel accumulates the BatchNorm-backward reduction in its epilogue when asked to (0: stand-alone kernel)
 int g_hp8_fill = 80;         // "hp8_fill": least percentage of the workgroup slots of its rounds (256 per round) that conv_igemm_hp8_kernel must fill
 int g_tile256_min = 129;     // "tile256_min": the one-round 8-wave tiles are taken from 256 * this many pixels on, i.e. as soon as the 128 x 128 tiling
@@ -165,6 +170,11 @@ struct ConvArgs {
   const float* red_beta = nullptr;
   const float* red_slope = nullptr;   // PReLU slopes or nullptr (plain BatchNorm)
   float* red_out = nullptr;       // [VLSFR_BN_REPL][3][Mrows], pre-zeroed
+  // Forward launches whose input is a BatchNorm (+ PReLU) of x applied in the operand path (vlsfr_conv2d_fwd_bnin, conv_igemm_hw4_kernel<XF>):
+  const float* xf_scale = nullptr;   // [C] gamma * invstd
+  const float* xf_shift = nullptr;   // [C] beta - mean * scale
+  const float* xf_slope = nullptr;   // [C] PReLU slopes or nullptr
+  u16* xf_out = nullptr;             // the transformed input [rows of x][C] bf16 as a by-product, or nullptr
   int repl = 1;                   // replicas of the per-channel accumulators in use (vlsfr::g_bn_repl)
   int dbg = 0;                    // diagnostics ("conv_dbg"): 4 skip the x-tile DMA, 8 skip the reduction arithmetic, 16 skip its atomics
 };
@@ -1558,6 +1568,11 @@ __global__ __launch_bounds__(512, 1) void conv_igemm_hp8_kernel(ConvArgs a, int 
 #endif
 }
 
+// slot of the input transform's micro-operations that gap n of step `step` (0 / 1) of a k-tile carries, or -1 (conv_igemm_hw4_kernel<XF>)
+constexpr int xf_seq(int step, int n) {
+  return step == 0 ? (n <= 14 ? n : (n >= 37 && n <= 55 ? 15 + (n - 37) : -1)) : (n >= 27 && n <= 52 ? 34 + (n - 27) : -1);
+}
+
 // MFMA with the accumulator pinned in the accumulator half of the register file ("+a"): with 224 accumulator registers and a
 // 120-register fragment double buffer per wave the compiler otherwise shuttles accumulator tiles between the two halves every
 // iteration (hundreds of v_accvgpr moves per k-tile).  Inline asm also fixes the instruction's place in the stream.
@@ -1592,7 +1607,15 @@ __device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
 // RED: an input-gradient launch that also accumulates the reduction of the BatchNorm backward reading its output (ConvArgs::red_x,
 // conv_epilogue): the [BN pixels][BM channels] tile of that layer's input is fetched by LDS-DMA into the (now free) LDS as soon as
 // the loop ends and lands under the output stores.
-template <int BM, int NT, int PPW, int DIAG = 0, bool RED = false>
+// XF (forward launches, vlsfr_conv2d_fwd_bnin): the input tensor is the RAW output of the layer in front and the BatchNorm (XF = 1) or
+// BatchNorm + PReLU (XF = 2) that stands between the two layers is applied to the patch IN LDS, once per element (the nine taps of
+// a chunk read the transformed patch) — what bn_apply did in a pass of its own over HBM.  The wave that fetched a 1 KiB piece owns it:
+// a lane's 16 bytes are always the same 8 channels of the chunk (lchunk), so scale / shift / slope sit in registers per chunk; the
+// piece fetched in tap t is read back from LDS in tap t + 1 (behind the barrier that drains the DMA), transformed in the MFMA
+// gaps of tap t + 2 (micro-operations of 2 - 3 VALU, one per gap) and written back in place — and, for passes that keep
+// activations, stored to a_out from the registers (rows of the tile proper only: every row of the tensor is written once).  Pieces
+// are fetched in taps 0..5 only, so the last one is back in LDS before the barrier of tap 8, behind which the new patch is first read.
+template <int BM, int NT, int PPW, int DIAG = 0, bool RED = false, int XF = 0>
 __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int PR, int lead) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool TRACE = DIAG == 1;
@@ -1603,12 +1626,15 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   constexpr int PA = BM / 8 / NW;            // LDS-DMA pieces of a weight tile per wave (8 rows each): 8 or 4
   constexpr int NMF = MT * NT;               // MFMAs per step
   constexpr int OOB = (int)0x80000000;
-  static_assert((BM == 256 || BM == 128) && NT >= 4 && NT <= 8 && (PPW == 1 || PPW == 2), "tile");
-  constexpr int DSTEP = BM == 256 ? 5 : 8;   // MFMA gaps between two LDS-DMA pieces of the second step
-  static_assert((PA + PPW - 1) * DSTEP < NMF && (PA + PPW - 1) * DSTEP + 6 <= NMF && PA + PPW + MT + NT + 5 <= NMF && MT + NT + 4 + 2 * NT + 3 * PPW <= NMF, "the side operations of a step fit its MFMA gaps");
+  static_assert((BM == 256 || BM == 128) && NT >= 4 && NT <= 8 && PPW >= 1 && PPW <= 3 && !(XF && RED), "tile");
+  constexpr int PT = XF ? 6 : 8;             // taps of a chunk in which pieces of the next patch are fetched
+  constexpr int XMP = XF == 2 ? 22 : XF == 1 ? 14 : 0;   // micro-operations of the transform of one piece
+  static_assert(XMP * PPW <= 120 && NMF == 56, "the transform of a tap's pieces fits its slots (xf_seq is laid out for 56 gaps per step)");
+  constexpr int DSTEP = BM == 256 ? 5 : (PPW == 3 ? 7 : 8);   // MFMA gaps between two LDS-DMA pieces of the second step
+  static_assert((PA + PPW - 1) * DSTEP < NMF && (PA + PPW - 1) * DSTEP + 6 < NMF && PA + PPW + MT + NT + 5 <= NMF && MT + NT + 4 + 2 * NT + 3 * PPW <= NMF, "the side operations of a step fit its MFMA gaps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PATCH = PR * RSB;
-  const int NPI = PR >> 3;                    // DMA pieces per patch (<= 32 PPW)
+  const int NPI = PR >> 3;                    // DMA pieces per patch (<= PT * NW * PPW)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1649,6 +1675,100 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   const int rowbytes = a.C * 2;
   const int pq = q0 + rsub;
   const int pq_off = pq * rowbytes + lchunk * 16;
+  // XF: transform constants of this lane's 8 channels of a chunk, and the transform of one 16-byte piece
+  float xs[8], xh[8], xl[8];
+  auto xf_load = [&](int chunk) __attribute__((always_inline)) {
+    if constexpr (XF != 0) {
+      // (inline asm loads: the compiler's own waitcnt insertion would put a vmcnt(0) in front of the first use in EVERY k-tile —
+      // a drain of the weight DMA issued half a k-tile earlier; the loads are issued in tap 0 and first used in tap 2, behind two of
+      // the loop's own counted waits, and the prologue waits explicitly)
+      const int ch = (chunk < nchunk ? chunk : nchunk - 1) * BK + lchunk * 8;
+      auto ld4 = [](const float* p) __attribute__((always_inline)) {
+        f32x4 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+        return v;
+      };
+      const f32x4 s0 = ld4(a.xf_scale + ch), s1 = ld4(a.xf_scale + ch + 4);
+      const f32x4 h0 = ld4(a.xf_shift + ch), h1 = ld4(a.xf_shift + ch + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xs[e] = s0[e];
+        xs[4 + e] = s1[e];
+        xh[e] = h0[e];
+        xh[4 + e] = h1[e];
+      }
+      if constexpr (XF == 2) {
+        const f32x4 l0 = ld4(a.xf_slope + ch), l1 = ld4(a.xf_slope + ch + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xl[e] = l0[e];
+          xl[4 + e] = l1[e];
+        }
+      }
+    }
+  };
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  // a_out descriptor: rows outside the tile proper (halo), outside the tensor, and every row when no a_out is wanted get an
+  // out-of-range offset — the store is dropped, no branch
+  const __amdgpu_buffer_rsrc_t rs_ao =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.xf_out, 0, a.xf_out ? (int)((size_t)P * a.C * 2) : 0, 0x00020000);
+  u32x4 xraw[PPW];          // pieces read back from LDS, waiting for / in their transform
+  float xf8[8];             // the piece in work
+  uint32_t xw_addr[PPW];    // where each goes back to (LDS), and its first pixel row relative to the patch (or far out of range)
+  int xw_q8[PPW];
+  int xw_soff[PPW];         // ... and its byte offset in x / a_out relative to this lane's pq_off
+  // micro-operation m of the transform of piece e (compile-time m): 4 x unpack, 4 x multiply-add, (8 x PReLU), 4 x pack, write, store
+  auto xf_micro = [&](auto e_tag, auto m_tag, int chunk) __attribute__((always_inline)) {
+    if constexpr (XF != 0) {
+      constexpr int e = decltype(e_tag)::value, m = decltype(m_tag)::value;
+      constexpr int M_FMA = 4, M_PRELU = 8, M_PACK = XF == 2 ? 16 : 8, M_WRITE = M_PACK + 4, M_STORE = M_WRITE + 1;
+      if constexpr (m < M_FMA) {
+        const uint32_t w = xraw[e][m];
+        xf8[2 * m] = __uint_as_float(w << 16);
+        xf8[2 * m + 1] = __uint_as_float(w & 0xffff0000u);
+        asm volatile("" : "+v"(xf8[2 * m]), "+v"(xf8[2 * m + 1]));
+      } else if constexpr (m < M_PRELU) {
+        constexpr int q = 2 * (m - M_FMA);
+        xf8[q] = xf8[q] * xs[q] + xh[q];                 // (the expression of bn_apply_kernel)
+        xf8[q + 1] = xf8[q + 1] * xs[q + 1] + xh[q + 1];
+        asm volatile("" : "+v"(xf8[q]), "+v"(xf8[q + 1]));
+      } else if constexpr (m < M_PACK) {                 // XF == 2 only
+        constexpr int q = m - M_PRELU;
+        const float z = xf8[q];
+        xf8[q] = z > 0.f ? z : z * xl[q];
+        asm volatile("" : "+v"(xf8[q]));
+      } else if constexpr (m < M_WRITE) {
+        constexpr int q = m - M_PACK;
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        bf16x2 o;
+        o[0] = (__bf16)xf8[2 * q];
+        o[1] = (__bf16)xf8[2 * q + 1];
+        xraw[e][q] = __builtin_bit_cast(uint32_t, o);
+        asm volatile("" : "+v"(xraw[e][q]));
+      } else if constexpr (m == M_WRITE) {
+        asm volatile("ds_write_b128 %0, %1" ::"v"(xw_addr[e] + (uint32_t)(lane * 16)), "v"(xraw[e]) : "memory");
+      } else if constexpr (m == M_STORE) {
+        const int q = pq + xw_q8[e];                                         // flattened pixel of this lane's row
+        const bool ok = (unsigned)(q - p0) < (unsigned)BN && q < P;
+        // (a_out has the layout of x: the byte offset is the one the piece was fetched from)
+        const int off = (pq_off + xw_soff[e]) | (ok ? 0 : OOB);
+        __builtin_amdgcn_raw_buffer_store_b128(xraw[e], rs_ao, off, 0, 0);
+      }
+    }
+  };
+  // The transform's micro-operations go to the gaps that carry little else: gaps 0..14 (one fragment read each) and 37..55 (empty) of
+  // a k-tile's first step, gaps 27..52 of its second (behind the DMA pieces and the fragment reads, in front of the read-back of
+  // the next pieces) — 60 slots in time order, XPER micro-operations each.
+  constexpr int XSLOTS = 60, XTOT = XMP * PPW, XPER = XF ? (XTOT + XSLOTS - 1) / XSLOTS : 1;
+  auto xf_slot = [&](auto s_tag, int chunk) __attribute__((always_inline)) {
+    constexpr int sidx = decltype(s_tag)::value;
+    if constexpr (XF != 0 && sidx >= 0) {
+      static_for<XPER>([&](auto kc) {
+        constexpr int m = sidx * XPER + decltype(kc)::value;
+        if constexpr (m < XTOT) xf_micro(std::integral_constant<int, m / XMP>{}, std::integral_constant<int, m % XMP>{}, chunk);
+      });
+    }
+  };
   // piece x (wave-uniform) of a patch; due == false: nothing to fetch — the instruction still issues (no branch in the stream), with an
   // out-of-range offset (no memory traffic, zeros) into the dump area behind the zero row
   auto stage_p = [&](int x, int cbyte, int pbuf, bool due) {
@@ -1760,7 +1880,21 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
 
   // ---- prologue: k-tile 0 and patch 0 complete; fragments of step 0
   // (k-tile 1's weight pieces, issued last, stay in flight: the loop's first barrier drains them; lgkmcnt: the zero row's ds_write)
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PA) : "memory");
+  if constexpr (XF != 0) {
+    // the whole first patch is transformed here, every wave its own pieces (x = wave, wave + 4, ...)
+    xf_load(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int x = wave; x < NPI; x += NW) {
+      const uint32_t ad = ldsP + (uint32_t)(x * 1024 + lane * 16);
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(xraw[0]) : "v"(ad) : "memory");
+      xw_addr[0] = ldsP + (uint32_t)(x * 1024);
+      xw_q8[0] = x * 8;
+      xw_soff[0] = x * 8 * rowbytes;
+      static_for<XMP>([&](auto mc) { xf_micro(std::integral_constant<int, 0>{}, mc, 0); });
+    }
+    xf_load(1);
+  }
+  if (nk > 1 && XF == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PA) : "memory");
   else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   static_for<MT>([&](auto ic) { read_a(B0{}, ic, rowA); });
@@ -1779,10 +1913,28 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   int t = 0, c = 0, tn = 1, trn = 0, tsn = 1, cn = 0;
   uint32_t sb = 0;
   int k2s = 0, a_voff = OOB;
+  const uint32_t dump = (uint32_t)(uintptr_t)(lds_void_t*)(sP + 2 * PATCH + 128);
   uint32_t p_dst[PPW];
   int p_soff[PPW];
+  int p_q8[PPW];                 // XF: first row of the piece relative to the patch (far out of range when no piece is due)
+  uint32_t xr_addr[PPW];         // XF: the pieces fetched in the previous tap (read back from LDS in this tap's second step) ...
+  int xr_q8[PPW];
+  int xr_soff[PPW];
+#pragma unroll
+  for (int e = 0; e < PPW; ++e) {
+    p_dst[e] = dump;
+    xr_addr[e] = dump;
+    xw_addr[e] = dump;
+    p_soff[e] = 0;
+    p_q8[e] = -(1 << 28);
+    xr_q8[e] = -(1 << 28);
+    xw_q8[e] = -(1 << 28);
+    xw_soff[e] = 0;
+    xr_soff[e] = 0;
+    if constexpr (XF != 0) asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0"
+                                        : "=v"(xraw[e][0]), "=v"(xraw[e][1]), "=v"(xraw[e][2]), "=v"(xraw[e][3]));
+  }
   int s_tmp0 = 0, s_tmp1 = 0, s_px = 0, s_due = 0;
-  const uint32_t dump = (uint32_t)(uintptr_t)(lds_void_t*)(sP + 2 * PATCH + 128);
   for (int u = 0; u < nk; ++u) {
     // ---- step 2u (k = 0..31 of this tap, fragments F[0]); reads of step 2u + 1 into F[1], then the next tap's addresses
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1816,22 +1968,32 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
       } else if constexpr (n >= G + 4 + 2 * NT && n < G + 4 + 2 * NT + 3 * PPW) {   // this tap's piece(s) of the next chunk's patch, three gaps each
         constexpr int e = (n - (G + 4 + 2 * NT)) / 3, part = (n - (G + 4 + 2 * NT)) % 3;
         if constexpr (part == 0) {
+          if constexpr (XF != 0) {        // the piece of the previous tap moves on to its read-back
+            xr_addr[e] = p_dst[e];
+            xr_q8[e] = p_q8[e];
+            xr_soff[e] = p_soff[e];
+          }
           s_px = (t * NW + wave) * PPW + e;
-          s_due = -((int)dma & (int)(t < 8) & (int)(c + 1 < nchunk) & (int)(s_px < NPI));      // all ones / zero (no branch)
+          s_due = -((int)dma & (int)(t < PT) & (int)(c + 1 < nchunk) & (int)(s_px < NPI));      // all ones / zero (no branch)
+          if constexpr (XF != 0) p_q8[e] = (s_px * 8 & s_due) | (-(1 << 28) & ~s_due);
           asm volatile("" : "+s"(s_px), "+s"(s_due));
         } else if constexpr (part == 1) {
           p_dst[e] = dump + ((ldsP + (uint32_t)(((c + 1) & 1) * PATCH + s_px * 1024) - dump) & (uint32_t)s_due);
           asm volatile("" : "+s"(p_dst[e]));
         } else {
           p_soff[e] = s_px * 8 * rowbytes + (c + 1) * (BK * 2);
-          asm volatile("" : "+s"(p_soff[e]));
+          // (no pin here: with the a_out store of the transform the compiler derives this sum from a per-lane one, and an "s" constraint then asks for an illegal VGPR -> SGPR copy)
         }
       }
+      if constexpr (XF != 0) xf_slot(std::integral_constant<int, xf_seq(0, n)>{}, c + 1);   // the transform of the pieces read back in the previous tap
       __builtin_amdgcn_sched_barrier(0);
     });
 
     // ---- step 2u + 1 (k = 32..63, fragments F[1]); the k-tile's barrier; DMA of k-tile u + 2 and of the patch piece; reads of step 2u + 2
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (XF: the PPW a_out stores of the step just finished are the youngest vector-memory operations and stay in flight — a store's
+    // acknowledgement takes longer than a k-tile; everything older, i.e. the DMA and the constants' loads, is drained)
+    if constexpr (XF != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (TRACE) {
       if (tr_on && u < 64) {
@@ -1854,16 +2016,32 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
         constexpr int e = n / DSTEP;
         if constexpr (e < PA) {
           // (no k-tile u + 2: out-of-range offset — no memory traffic, zeros into the buffer nobody reads again)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + sb + (e * NW + wave) * 1024), 16, a_voff,
-                                                   k2s + e * a_estep, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_void_t*)(smem + __builtin_amdgcn_readfirstlane(sb) + (e * NW + wave) * 1024), 16,
+                                                   a_voff, __builtin_amdgcn_readfirstlane(k2s) + e * a_estep, 0, 0);
         } else {
           // rows in front of the tensor or behind it: the offset itself is out of the descriptor's range (negative pq_off wraps)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(uintptr_t)p_dst[e - PA], 16, pq_off + p_soff[e - PA], 0, 0, 0);
+          // (readfirstlane: the values are uniform; it keeps the compiler from wrapping the instruction in a waterfall loop when its
+          // own analysis has lost track of that)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)(uintptr_t)__builtin_amdgcn_readfirstlane(p_dst[e - PA]), 16,
+                                                   pq_off + p_soff[e - PA], 0, 0, 0);
         }
       } else if constexpr (rd < MT) {
         read_a(B0{}, std::integral_constant<int, rd>{}, rowA + (sb ^ (uint32_t)ASTAGE));
       } else if constexpr (rd < MT + NT) {
         read_b(B0{}, std::integral_constant<int, rd - MT>{}, addrB[rd - MT]);
+      }
+      if constexpr (XF != 0) {
+        // the rest of the transform of the previous tap's pieces (the slots of this step) ...
+        xf_slot(std::integral_constant<int, xf_seq(1, n)>{}, c + 1);
+        // ... and, behind it (gaps NMF - PPW ..), the read-back of the pieces this wave fetched in the previous tap: landed (the wait at
+        // the head of this step), transformed during the next k-tile
+        if constexpr (n >= NMF - PPW) {
+          constexpr int e = n - (NMF - PPW);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(xraw[e]) : "v"(xr_addr[e] + (uint32_t)(lane * 16)) : "memory");
+          xw_addr[e] = xr_addr[e];
+          xw_q8[e] = xr_q8[e];
+          xw_soff[e] = xr_soff[e];
+        }
       }
       // behind the last LDS-DMA gap (its destination is this k-tile's buffer sb): the next k-tile becomes this one
       constexpr int ADV = (ND - 1) * DSTEP + 1 > ND + MT + NT ? (ND - 1) * DSTEP + 1 : ND + MT + NT;
@@ -1891,6 +2069,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
         trn = z ? 0 : trn;
         tsn = z ? 0 : tsn;
         asm volatile("" : "+s"(tsn), "+s"(trn));
+      } else if constexpr (XF != 0 && n == ADV + 5) {
+        if (t == 0) xf_load(c + 1);                        // a chunk begins: the constants of the patch fetched during it (first used in tap 2)
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -2673,9 +2853,13 @@ int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
   constexpr int BN = (4 / (BM / 128)) * NT * 16;
   const int lead = hp8_lead(BN, a.W), PR = hp8_patch_rows(BN, a.W);
   const int lds = hp8_lds_bytes(BM, BN, a.W) + 1024;   // + the dump area of the LDS-DMA pieces that have nothing to fetch
-  auto kern = red       ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0, true> : conv_igemm_hw4_kernel<BM, NT, 1, 0, true>)
-              : a.trace ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
-                        : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
+  // pieces of the next patch per wave and tap: 8 x 4 x PPW slots per chunk, 6 x 4 x PPW with the input transform (XF)
+  constexpr int XPPW = BM == 256 ? 2 : 3;
+  if (a.xf_scale && PR / 8 > 24 * XPPW) return fail(VLSFR_EINVAL, "conv_igemm_hw4: patch of %d rows does not fit the transform's piece slots", PR);
+  auto kern = a.xf_scale ? (a.xf_slope ? conv_igemm_hw4_kernel<BM, NT, XPPW, 0, false, 2> : conv_igemm_hw4_kernel<BM, NT, XPPW, 0, false, 1>)
+              : red      ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0, true> : conv_igemm_hw4_kernel<BM, NT, 1, 0, true>)
+              : a.trace  ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
+                         : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
   if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_hw4")) return rc;
   dim3 grid((P + BN - 1) / BN, a.Mrows / BM, 1);
   ConvArgs b = a;
@@ -2705,6 +2889,18 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
   dim3 grid((P + BN - 1) / BN, (a.Mrows + BM - 1) / BM, a.splitk);
   if (a.C % 64 == 0) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 64>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, 32>), grid, dim3(256), 0, st, a);
+}
+
+// Rows of the halo-patch kernels' tile (256 / 128) for this convolution, or 0: 3x3 / stride 1 / pad 1, 256-row tiles x 224 pixels or
+// 128-row tiles x 448 pixels, where those tiles fill at least g_hp8_fill % of the workgroup slots of their rounds
+int hp8_tile_rows(int Mrows, int C, int H, int W, int Ho, int Wo, int R, int S, int stride, int pad, int P) {
+  if (!g_conv_hp8 || !(R == 3 && S == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && H >= 2 && C % 64 == 0)) return 0;
+  const int bm = (Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (Mrows == 128 && g_conv_hp8 != 2) ? 128 : 0;
+  if (!bm) return 0;
+  const int bn = bm == 256 ? 224 : 448;
+  const long tiles = (long)((P + bn - 1) / bn) * (Mrows / bm), rounds = (tiles + 255) / 256;
+  if (hp8_lds_bytes(bm, bn, W) + 1024 <= 160 * 1024 && hp8_patch_rows(bn, W) <= 512 && tiles * 100 >= rounds * 256 * g_hp8_fill) return bm;
+  return 0;
 }
 
 // red_done (optional): set to whether this launch accumulated the BatchNorm-backward reduction of ConvArgs::red_x (only the
@@ -2740,15 +2936,10 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   // layers, 448 on the 128-channel 28 x 28 layers).  A launch that wants the fused BatchNorm-backward reduction takes the
   // stand-alone reduction kernel instead (red_done stays false), as with the one-round tiles below.
   int hp8_bm = 0;
-  if (glds_ok && !halo_ok && variant_default && g_conv_hp8 && !a.tap_mask && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 &&
-      a.splitk == 1 && !a.out_f32 && a.Ho == a.H && a.Wo == a.W && a.H >= 2 && !(g_bnred_all && !(g_conv_hw4 && g_hw4_red))) {
-    const int bm = (a.Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (a.Mrows == 128 && g_conv_hp8 != 2) ? 128 : 0;
-    if (bm) {
-      const int bn = bm == 256 ? 224 : 448;
-      const long tiles = (long)((P + bn - 1) / bn) * (a.Mrows / bm), rounds = (tiles + 255) / 256;
-      if (hp8_lds_bytes(bm, bn, a.W) + 1024 <= 160 * 1024 && hp8_patch_rows(bn, a.W) <= 512 && tiles * 100 >= rounds * 256 * g_hp8_fill) hp8_bm = bm;
-    }
-  }
+  if (glds_ok && !halo_ok && variant_default && !a.tap_mask && a.splitk == 1 && !a.out_f32 && !(g_bnred_all && !(g_conv_hw4 && g_hw4_red)))
+    hp8_bm = hp8_tile_rows(a.Mrows, a.C, a.H, a.W, a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, P);
+  if (a.xf_scale && !(hp8_bm && g_conv_hw4))
+    return fail(VLSFR_EINVAL, "conv_igemm: the fused input BatchNorm needs conv_igemm_hw4_kernel (vlsfr_conv2d_fwd_bnin_supported)");
   // (one round of one tile per CU: the tile count over BOTH grid dimensions is bounded by the 256 CUs — 512 output channels at
   // >= 33 024 pixels would be two rounds, the case the 128 x 128 tiles win)
   const bool tile256_here = !hp8_bm && glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
@@ -2905,6 +3096,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "conv_hw4")) {
     g_conv_hw4 = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_bnin")) {
+    g_conv_bnin = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "hw4_red")) {
@@ -3073,6 +3268,50 @@ int vlsfr_conv2d_fwd(const vlsfr_conv_desc* d, const void* x, const void* w, voi
   a.splitk = splitk;
   a.out_f32 = out_f32;
   a.stats = stats;
+  return run_igemm(a, (hipStream_t)stream);
+}
+
+int32_t vlsfr_conv2d_fwd_bnin_supported(const vlsfr_conv_desc* d) {
+  if (!d || conv_check(d, "vlsfr_conv2d_fwd_bnin_supported")) return 0;
+  if (!(g_use_glds == VLSFR_DEFAULT_CONV_VARIANT && g_conv_hw4 && g_conv_bnin)) return 0;   // (the executors ask here: "conv_bnin" = 0 keeps them on bn_apply)
+  const int Ho = out_dim(d->H, d->R, d->stride, d->pad), Wo = out_dim(d->W, d->S, d->stride, d->pad);
+  const size_t P = (size_t)d->N * Ho * Wo;
+  if (d->Cin % 64 || (size_t)d->N * d->H * d->W * d->Cin >= (1ull << 30) || (size_t)d->Cout * 9 * d->Cin >= (1ull << 30)) return 0;
+  const int bm = hp8_tile_rows(d->Cout, d->Cin, d->H, d->W, Ho, Wo, d->R, d->S, d->stride, d->pad, (int)P);
+  if (!bm) return 0;
+  const int bn = bm == 256 ? 224 : 448;
+  return hp8_patch_rows(bn, d->W) / 8 <= 24 * (bm == 256 ? 2 : 3);
+}
+
+int vlsfr_conv2d_fwd_bnin(const vlsfr_conv_desc* d, const void* x, const void* w, void* y, double* stats, const vlsfr_bn_in* bn,
+                          void* stream) {
+  int rc = conv_check(d, "vlsfr_conv2d_fwd_bnin");
+  if (rc) return rc;
+  if (!x || !w || !y || !bn || !bn->scale || !bn->shift) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd_bnin: null buffer");
+  if (!vlsfr_conv2d_fwd_bnin_supported(d)) return fail(VLSFR_EINVAL, "vlsfr_conv2d_fwd_bnin: shape not covered (vlsfr_conv2d_fwd_bnin_supported)");
+  ConvArgs a;
+  a.x = (const u16*)x;
+  a.w = (const u16*)w;
+  a.y = y;
+  a.Nimg = d->N;
+  a.H = d->H;
+  a.W = d->W;
+  a.C = d->Cin;
+  a.Ho = d->H;
+  a.Wo = d->W;
+  a.Mrows = d->Cout;
+  a.R = d->R;
+  a.S = d->S;
+  a.stride = d->stride;
+  a.pad = d->pad;
+  a.mode = 0;
+  a.splitk = 1;
+  a.out_f32 = 0;
+  a.stats = stats;
+  a.xf_scale = bn->scale;
+  a.xf_shift = bn->shift;
+  a.xf_slope = bn->slope;
+  a.xf_out = (u16*)bn->a_out;
   return run_igemm(a, (hipStream_t)stream);
 }
 

@@ -365,17 +365,35 @@ int bn_backward(const Bn& b, const void* dy, const void* x, void* dx, int64_t M,
 
 // IBasicBlock.forward (resnet_arcface.py:44-55) of block k on the activation `cur` (bf16 NHWC; its statistics are already in
 // bn1's sums: every BatchNorm's batch statistics are accumulated by the kernel that PRODUCES its input)
+// y = conv(bn(x)) (+ PReLU between them): where the convolution kernel can apply the BatchNorm in its operand path
+// (vlsfr_conv2d_fwd_bnin: the 3x3 / stride-1 layers on conv_igemm_hw4_kernel) only the per-channel part of the BatchNorm runs as a
+// kernel of its own (vlsfr_bn_finalize, one workgroup) and the normalised tensor `a` comes out of the convolution as a by-product —
+// or not at all in a pass that keeps no activations (keep == false: the gallery passes); elsewhere bn_apply + conv as before.
+int bn_conv_forward(const Bn& bn, const Conv& cv, const char* x, char* a_buf, char* y, double* y_sums, int64_t M, int HW, bool keep,
+                    const float* const* params, float* const* running, char* ctx, const char* wc, void* st) {
+  if (vlsfr_conv2d_fwd_bnin_supported(&cv.d)) {
+    float* rm = running ? running[2 * bn.run] : nullptr;
+    float* rv = running ? running[2 * bn.run + 1] : nullptr;
+    RUN(vlsfr_bn_finalize((const double*)(ctx + bn.off_sums), M, bn.C, params[bn.p_w], params[bn.p_b], BN_EPS, BN_MOM,
+                          (float*)(ctx + bn.off_mean), (float*)(ctx + bn.off_invstd), (float*)(ctx + bn.off_scale),
+                          (float*)(ctx + bn.off_shift), rm, rv, st));
+    const vlsfr_bn_in in{(const float*)(ctx + bn.off_scale), (const float*)(ctx + bn.off_shift),
+                         bn.p_slope >= 0 ? params[bn.p_slope] : nullptr, keep ? a_buf : nullptr};
+    return vlsfr_conv2d_fwd_bnin(&cv.d, x, wc + cv.off_wb, y, y_sums, &in, st);
+  }
+  RUN(bn_forward(bn, x, a_buf, M, HW, nullptr, nullptr, 0, params, running, ctx, st));
+  return vlsfr_conv2d_fwd(&cv.d, a_buf, wc + cv.off_wb, y, 1, 0, y_sums, st);
+}
+
 int forward_block(const vlsfr_iresnet* n, int k, const char* cur, const float* const* params, float* const* running, char* ctx,
-                  const char* wc, const Scratch& sc, void* st) {
+                  const char* wc, const Scratch& sc, void* st, bool keep = true) {
   const int B = n->B;
   auto sums_of = [&](const Bn& b) { return (double*)(ctx + b.off_sums); };
   const Block& b = n->blocks[k];
   const Bn& next_bn = (size_t)k + 1 < n->blocks.size() ? n->blocks[k + 1].bn1 : n->bn_last;
   const int64_t Min = (int64_t)B * b.H * b.W, Mout = (int64_t)B * b.Ho * b.Wo;
-  RUN(bn_forward(b.bn1, cur, ctx + b.a1, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
-  RUN(vlsfr_conv2d_fwd(&b.conv1.d, ctx + b.a1, wc + b.conv1.off_wb, ctx + b.c1, 1, 0, sums_of(b.bn2), st));
-  RUN(bn_forward(b.bn2, ctx + b.c1, ctx + b.a2, Min, b.H * b.W, nullptr, nullptr, 0, params, running, ctx, st));
-  RUN(vlsfr_conv2d_fwd(&b.conv2.d, ctx + b.a2, wc + b.conv2.off_wb, ctx + b.c2, 1, 0, sums_of(b.bn3), st));
+  RUN(bn_conv_forward(b.bn1, b.conv1, cur, ctx + b.a1, ctx + b.c1, sums_of(b.bn2), Min, b.H * b.W, keep, params, running, ctx, wc, st));
+  RUN(bn_conv_forward(b.bn2, b.conv2, ctx + b.c1, ctx + b.a2, ctx + b.c2, sums_of(b.bn3), Min, b.H * b.W, keep, params, running, ctx, wc, st));
   const void* idn = cur;
   if (b.has_ds) {
     RUN(vlsfr_conv2d_fwd(&b.convd.d, cur, wc + b.convd.off_wb, ctx + b.cs, 1, 0, sums_of(b.bnd), st));
@@ -482,6 +500,12 @@ int vlsfr_iresnet_prepare_weights(const vlsfr_iresnet* n, const float* const* pa
 int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params,
                           float* const* running, const void* wcache, void* ctx_v, void* scratch, float* emb_out,
                           void* st) {
+  return vlsfr_iresnet_forward_ex(n, x_nchw, params, running, wcache, ctx_v, scratch, emb_out, 1, st);
+}
+
+int vlsfr_iresnet_forward_ex(const vlsfr_iresnet* n, const float* x_nchw, const float* const* params,
+                             float* const* running, const void* wcache, void* ctx_v, void* scratch, float* emb_out,
+                             int32_t keep_activations, void* st) {
   if (!n || !x_nchw || !params || !wcache || !ctx_v || !scratch || !emb_out)
     return fail(VLSFR_EINVAL, "vlsfr_iresnet_forward: null argument");
   char* ctx = (char*)ctx_v;
@@ -500,7 +524,7 @@ int vlsfr_iresnet_forward(const vlsfr_iresnet* n, const float* x_nchw, const flo
                  sums_of(n->blocks[0].bn1), 0, params, running, ctx, st));
   const char* cur = ctx + n->off_a0;
   for (size_t k = 0; k < n->blocks.size(); ++k) {
-    RUN(forward_block(n, (int)k, cur, params, running, ctx, wc, sc, st));
+    RUN(forward_block(n, (int)k, cur, params, running, ctx, wc, sc, st, keep_activations != 0));
     cur = ctx + n->blocks[k].out;
   }
   // bn2 -> flatten -> fc -> features -> normalise (resnet_arcface.py:147-151)

@@ -252,6 +252,38 @@ struct BnApplyArgs {
   int repl;               // replicas in use (vlsfr::g_bn_repl)
 };
 
+// The per-channel part of bn_apply on its own (vlsfr_bn_finalize): statistics -> mean / invstd (saved), scale / shift, running
+// statistics.  For a BatchNorm whose element-wise part runs inside the consumer convolution (vlsfr_conv2d_fwd_bnin).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sums, int64_t M, int C, int repl, const float* gamma, const float* beta,
+                                                          float eps, float momentum, float* save_mean, float* save_invstd, float* scale,
+                                                          float* shift, float* running_mean, float* running_var) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+    double sd = 0.0, qd = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < repl; ++r) {
+      sd += sums[(size_t)r * 2 * C + c];
+      qd += sums[(size_t)r * 2 * C + C + c];
+    }
+    const double mean_d = sd / (double)M;
+    double var_d = qd / (double)M - mean_d * mean_d;
+    var_d = var_d > 0.0 ? var_d : 0.0;
+    const float mean = (float)mean_d;
+    const float var = (float)var_d;
+    const float invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - mean * g * invstd;
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (running_mean) {
+      const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+  }
+}
+
 // FLAGS (compile time, so that the streaming loop is one straight-line block): 1 PReLU, 2 residual,
 // 4 statistics of y, 8 flatten-order (NCHW) output, 16 ReLU after the residual add (with 2; not with 1 / 4)
 template <int FLAGS>
@@ -891,6 +923,17 @@ int vlsfr_bn_apply(const void* x, void* y, int64_t M, int32_t C, int32_t HW, con
   }
 #undef VLSFR_CASE
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_apply");
+  return VLSFR_OK;
+}
+
+int vlsfr_bn_finalize(const double* sums, int64_t M, int32_t C, const float* gamma, const float* beta, float eps, float momentum,
+                      float* save_mean, float* save_invstd, float* scale, float* shift, float* running_mean, float* running_var,
+                      void* stream) {
+  if (!sums || !save_mean || !save_invstd || !scale || !shift || M <= 0 || C <= 0)
+    return fail(VLSFR_EINVAL, "vlsfr_bn_finalize: bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, M, C, vlsfr::g_bn_repl, gamma, beta,
+                     eps, momentum, save_mean, save_invstd, scale, shift, running_mean, running_var);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_bn_finalize");
   return VLSFR_OK;
 }
 

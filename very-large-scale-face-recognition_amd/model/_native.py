@@ -276,6 +276,9 @@ class NativeBackbone(nn.Module):
             emb = torch.empty(B, self.feat_dim, dtype=torch.float32, device=x.device)
             fwd = getattr(L, self._cprefix + "_forward")
             fwd.restype = ctypes.c_int
+            fwd_ex = getattr(L, self._cprefix + "_forward_ex", None)      # executors that can skip what only a backward pass reads
+            if fwd_ex is not None:
+                fwd_ex.restype = ctypes.c_int
             if not self.training:
                 run_tab = None
             elif chain is not None:
@@ -288,10 +291,15 @@ class NativeBackbone(nn.Module):
                                lambda: (tuple(p.data_ptr() for p in params), None if run_tab is None else tuple(run_tab),
                                         self._wcache.data_ptr(), ws.data_ptr(), scratch.data_ptr()),
                                x, emb,
-                               lambda xin, out: _lib.check(fwd(h, ctypes.c_void_p(xin.data_ptr()), _ptr_array(params), run_tab,
-                                                               ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
-                                                               ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(out.data_ptr()), _stream()),
-                                                           self._cprefix + "_forward"))
+                               lambda xin, out: _lib.check(
+                                   fwd(h, ctypes.c_void_p(xin.data_ptr()), _ptr_array(params), run_tab,
+                                       ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                       ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(out.data_ptr()), _stream())
+                                   if fwd_ex is None or save else
+                                   fwd_ex(h, ctypes.c_void_p(xin.data_ptr()), _ptr_array(params), run_tab,
+                                          ctypes.c_void_p(self._wcache.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                                          ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_int32(0), _stream()),
+                                   self._cprefix + "_forward"))
         if self.training:
             self._nbt_pending += 1          # num_batches_tracked is materialised lazily (flush_counters)
         self.__dict__.setdefault("_keep", {})[k] = x      # the input outlives the asynchronous pass

@@ -56,6 +56,35 @@ def conv2d_fwd(x, w, desc, splitk=1, out_f32=False, stats=None):
     return y
 
 
+class BnIn(ctypes.Structure):      # vlsfr_bn_in
+    _fields_ = [(n, ctypes.c_void_p) for n in ("scale", "shift", "slope", "a_out")]
+
+
+def conv2d_fwd_bnin_supported(desc):
+    L = _lib.lib()
+    L.vlsfr_conv2d_fwd_bnin_supported.restype = ctypes.c_int32
+    return bool(L.vlsfr_conv2d_fwd_bnin_supported(ctypes.byref(desc)))
+
+
+def conv2d_fwd_bnin(x, w, desc, scale, shift, slope=None, want_a=True, stats=None):
+    """y = conv(prelu(x * scale + shift)) with the BatchNorm / PReLU applied in the kernel's operand path (vlsfr_conv2d_fwd_bnin).
+    Returns (y, a) with a = the transformed input (bf16) or None."""
+    y = torch.empty(desc.N, desc.H, desc.W, desc.Cout, dtype=torch.bfloat16, device=x.device)
+    a = torch.zeros(desc.N, desc.H, desc.W, desc.Cin, dtype=torch.bfloat16, device=x.device) if want_a else None
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    b = BnIn(ptr(scale), ptr(shift), ptr(slope), ptr(a))
+    _call("vlsfr_conv2d_fwd_bnin", ctypes.byref(desc), _p(x), _p(w), _p(y), _p(stats), ctypes.byref(b), _st())
+    return y, a
+
+
+def bn_finalize(sums, M, C, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    dev = sums.device
+    mean, invstd, scale, shift = (torch.empty(C, dtype=torch.float32, device=dev) for _ in range(4))
+    _call("vlsfr_bn_finalize", _p(sums), ctypes.c_int64(M), ctypes.c_int32(C), _p(gamma), _p(beta), ctypes.c_float(eps),
+          ctypes.c_float(momentum), _p(mean), _p(invstd), _p(scale), _p(shift), _p(running_mean), _p(running_var), _st())
+    return mean, invstd, scale, shift
+
+
 def conv2d_dgrad(dy, wT, desc):
     dx = torch.empty(desc.N, desc.H, desc.W, desc.Cin, dtype=torch.bfloat16, device=dy.device)
     _call("vlsfr_conv2d_dgrad", ctypes.byref(desc), _p(dy), _p(wT), _p(dx), _st())
