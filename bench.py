@@ -28,7 +28,21 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (block-scaled v_mfma_scale_*_f8f6f4 forms), same table
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # per-launch HBM bytes of this round's kernels (scripts/profile_round.sh)
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # per-launch HBM bytes of this round's kernels (scripts/profile_round.sh / pmc_only.sh)
+
+
+def kernel_source_sha():
+    """Hash of csrc/ + include/ (scripts/pmc_traffic.py writes the same into the traffic file): the PMC figure is attached only
+    when it was collected on exactly these kernel sources — a stale file yields traffic = null, not an old number."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "very-large-scale-face-recognition_amd", "csrc", "*.[hc]*")) +
+                     glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if os.path.isfile(fn):
+            h.update(os.path.basename(fn).encode())
+            h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def host_threads():
@@ -482,8 +496,13 @@ def main():
         with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
             pt = json.load(f)
         if pt["config"] == {"net": args.net, "batch": B, "identities": args.identities}:
-            roofline["traffic"] = pt["kernels"][dom.replace("_kernel", "")]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command)" % PMC_TRAFFIC_FILE
+            if pt.get("source_sha") == kernel_source_sha():
+                roofline["traffic"] = pt["kernels"][dom.replace("_kernel", "")]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes of this command, "
+                                              "collected on these kernel sources: sha %s)" % (PMC_TRAFFIC_FILE, pt["source_sha"]))
+            else:
+                roofline["traffic_source"] = "profiles/%s is from other kernel sources (sha %s, here %s): not attached" % (
+                    PMC_TRAFFIC_FILE, pt.get("source_sha"), kernel_source_sha())
     except (OSError, KeyError, ValueError):
         pass
     faces = world * 2 * B * args.steps

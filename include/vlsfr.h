@@ -395,9 +395,11 @@ int vlsfr_bn_backward_reduce(const void* dy, const void* x, int64_t M, int32_t C
                              const float* invstd, const float* gamma, const float* beta, const float* slope, float* red,
                              void* stream);
 int vlsfr_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
-/* Zero fill by a kernel launch (16-byte aligned p): what the executors use for their accumulator regions, so that a pass
- * captured into a HIP graph consists of kernel and device-to-device copy nodes only. */
+/* Zero fill / device-to-device copy by a kernel launch (16-byte aligned pointers; the copy also a 16-byte multiple): what the
+ * executors use for their accumulator regions and to hand out the embedding, so that a pass captured into a HIP graph consists of
+ * kernel nodes only. */
 int vlsfr_zero_bytes(void* p, size_t nbytes, void* stream);
+int vlsfr_copy_bytes(const void* src, void* dst, size_t nbytes, void* stream);
 /* e = normalize(bn1d(fc + fc_bias)); all fp32 [B, D] */
 int vlsfr_embed_fwd(const float* fc, const float* fc_bias, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float* z, float* xhat, float* invstd,

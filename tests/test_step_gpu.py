@@ -214,6 +214,27 @@ def test_graph_replay_equals_plain_launches(tag):
     assert s0 == s1 and (q0 == q1).all()
 
 
+@pytest.mark.parametrize("tag", ["irtiny", "mobile"])
+def test_graph_replay_returns_the_plain_embedding(tag):
+    """The embedding a captured forward pass hands out (a copy KERNEL out of the executor's buffer, no runtime copy node) against
+    plain launches on the same input: equal up to what two plain launches differ by themselves (the float64 statistics are summed
+    atomically: their order is the only noise), on every replay — a stale or half-written embedding would be off by orders more."""
+    z = np.load(os.path.join(G, "step_%s.npz" % tag))
+    m, x, y, xl, yl = build_ffc(z, tag)
+    net = m.gallery_net
+    with torch.no_grad():
+        plain = [net(x).clone() for _ in range(3)]
+        noise = max(float((plain[0] - p).abs().max()) for p in plain[1:])
+        net.use_graphs = True
+        got = [net(x).clone() for _ in range(8)]          # 2 eager warm-ups, capture, 5 replays
+        torch.cuda.synchronize()
+        assert any(k[0] == "fwd" and st["graph"] is not None for k, st in net._graphs.items())
+        net.use_graphs = False
+    for g in got:
+        assert float((g - plain[0]).abs().max()) <= max(4 * noise, 1e-6), (float((g - plain[0]).abs().max()), noise)
+    assert float((net(x) - plain[0]).abs().max()) <= max(4 * noise, 1e-6)
+
+
 def test_ir18_two_steps_vs_oracle():
     """A deeper net (ir18), two consecutive steps, against the float64 oracle: loss trajectory,
     LRU / queue_position state, embedding cosine."""

@@ -333,9 +333,8 @@ int vlsfr_mobilenet_forward(const vlsfr_mobilenet* n, const float* x_nchw, const
                       running ? running[2 * n->l1_run + 1] : nullptr, (float*)(ctx + n->off_z),
                       (float*)(ctx + n->off_xhat), (float*)(ctx + n->off_invstd), (float*)(ctx + n->off_emb),
                       (float*)(ctx + n->off_invnorm), n->B, n->D, BN_EPS, BN_MOM, st));
-  e = hipMemcpyAsync(emb_out, ctx + n->off_emb, (size_t)n->B * n->D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_mobilenet_forward: copy: %s", hipGetErrorString(e));
-  return VLSFR_OK;
+  (void)e;
+  return vlsfr_copy_bytes(ctx + n->off_emb, emb_out, (size_t)n->B * n->D * 4, st);   // (a kernel: captured passes hold no runtime copy nodes)
 }
 
 int vlsfr_mobilenet_backward(const vlsfr_mobilenet* n, const float* demb, const float* const* params,

@@ -608,6 +608,12 @@ __global__ __launch_bounds__(256) void zero_kernel(uint4* p, int64_t n16, char* 
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
 
+// device-to-device copy as a KERNEL (16-byte granules): the executors hand the embedding to the caller with it, so that a pass
+// captured into a HIP graph holds kernel nodes only (no runtime copy nodes: ADVICE r03)
+__global__ __launch_bounds__(256) void copy_kernel(const uint4* src, uint4* dst, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void add_bf16_kernel(const u16* p, const u16* q, u16* y, int64_t n8) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     bf8 u, v;
@@ -1009,6 +1015,18 @@ int vlsfr_zero_bytes(void* p, size_t nbytes, void* stream) {
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)p, n16, (char*)p + n16 * 16, ntail);
   VLSFR_HIP_CHECK_LAUNCH("vlsfr_zero_bytes");
+  return VLSFR_OK;
+}
+
+int vlsfr_copy_bytes(const void* src, void* dst, size_t nbytes, void* stream) {
+  if (!src || !dst || (((uintptr_t)src | (uintptr_t)dst | nbytes) & 15))
+    return fail(VLSFR_EINVAL, "vlsfr_copy_bytes: 16-byte aligned pointers and size");
+  if (nbytes == 0) return VLSFR_OK;
+  const int64_t n16 = (int64_t)(nbytes / 16);
+  int64_t blocks = (n16 + 256 * 4 - 1) / (256 * 4);
+  blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+  hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
+  VLSFR_HIP_CHECK_LAUNCH("vlsfr_copy_bytes");
   return VLSFR_OK;
 }
 

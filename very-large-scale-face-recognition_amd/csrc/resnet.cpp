@@ -346,9 +346,8 @@ int vlsfr_resnet_forward(const vlsfr_resnet* n, const float* x_nchw, const float
   RUN(vlsfr_embed_fwd((const float*)(ctx + n->off_fcout), params[n->p_fc_b], params[n->p_feat_w], params[n->p_feat_b], rm, rv,
                       (float*)(ctx + n->off_z), (float*)(ctx + n->off_xhat), (float*)(ctx + n->off_feat_invstd),
                       (float*)(ctx + n->off_emb), (float*)(ctx + n->off_invnorm), B, n->D, BN_EPS, BN_MOM, st));
-  e = hipMemcpyAsync(emb_out, ctx + n->off_emb, (size_t)B * n->D * 4, hipMemcpyDeviceToDevice, (hipStream_t)st);
-  if (e != hipSuccess) return fail(VLSFR_EHIP, "vlsfr_resnet_forward: copy: %s", hipGetErrorString(e));
-  return VLSFR_OK;
+  (void)e;
+  return vlsfr_copy_bytes(ctx + n->off_emb, emb_out, (size_t)B * n->D * 4, st);   // (a kernel: captured passes hold no runtime copy nodes)
 }
 
 int vlsfr_resnet_backward(const vlsfr_resnet* n, const float* demb, const float* const* params, float* const* grads,
