@@ -437,9 +437,11 @@ def test_conv_four_phase_kernel_short_loops_and_stride(cin, k, stride, hw):
 # fused BatchNorm statistics) and the input gradient, with full tiles, a ragged last tile, tiles that start in the middle of a
 # line (W does not divide the tile: the patch then carries W + 1 halo rows) and tiles that span several images.
 @pytest.mark.parametrize("cin,cout,hw,N", [(256, 256, 14, 256), (256, 256, 14, 37), (128, 128, 28, 64), (128, 128, 28, 9),
-                                           (256, 256, 10, 20), (128, 128, 12, 30), (128, 256, 7, 40), (64, 128, 28, 7), (256, 512, 14, 16)],
+                                           (256, 256, 10, 20), (128, 128, 12, 30), (128, 256, 7, 40), (64, 128, 28, 7), (256, 512, 14, 16),
+                                           (64, 64, 56, 8), (64, 64, 112, 2), (64, 64, 28, 5), (64, 64, 10, 37)],
                          ids=["256ch-14-exact", "256ch-14-ragged", "128ch-28-exact", "128ch-28-ragged", "256ch-10-unaligned",
-                              "128ch-12-unaligned", "256ch-7-multi-image", "64to128-28", "256to512-14"])
+                              "128ch-12-unaligned", "256ch-7-multi-image", "64to128-28", "256to512-14",
+                              "64ch-56", "64ch-112", "64ch-28-ragged", "64ch-10-unaligned"])
 def test_conv_halo_patch_four_phase_kernel_is_bit_identical(cin, cout, hw, N):
     import ctypes
     from vlsfr_amd import ops, _lib
@@ -469,7 +471,7 @@ def test_conv_halo_patch_four_phase_kernel_is_bit_identical(cin, cout, hw, N):
         setopt(b"hp8_fill", 80)
     assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[2][1], outs[0][1])
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
-    for s0 in sorted({0, N // 2, N - n}):       # and the small-batch kernel on slices (a convolution is independent per image)
+    for s0 in sorted({0, min(N // 2, N - n), N - n}):       # and the small-batch kernel on slices (a convolution is independent per image)
         assert torch.equal(ops.conv2d_fwd(x[s0:s0 + n].contiguous(), wb, small), outs[1][0][s0:s0 + n])
         assert torch.equal(ops.conv2d_dgrad(dy[s0:s0 + n].contiguous(), wT, small), outs[1][1][s0:s0 + n])
     yf = outs[1][0].double().reshape(-1, cout)
@@ -739,8 +741,10 @@ def _check_bnred(cin, cout, k, stride, hw, N, prelu):
 
 
 @pytest.mark.parametrize("cin,cout,hw,N,prelu", [(256, 256, 14, 37, True), (256, 256, 14, 32, False), (128, 128, 28, 9, True),
-                                                 (128, 128, 28, 16, False), (256, 128, 12, 30, True), (512, 256, 14, 16, True)],
-                         ids=["256ch-ragged-prelu", "256ch-exact", "128ch-ragged-prelu", "128ch-exact", "128ch-unaligned", "256-rows-of-512-cout"])
+                                                 (128, 128, 28, 16, False), (256, 128, 12, 30, True), (512, 256, 14, 16, True),
+                                                 (64, 64, 56, 5, True), (64, 64, 112, 2, False)],
+                         ids=["256ch-ragged-prelu", "256ch-exact", "128ch-ragged-prelu", "128ch-exact", "128ch-unaligned", "256-rows-of-512-cout",
+                              "64ch-56-prelu", "64ch-112"])
 def test_dgrad_bnred_in_the_one_wave_per_simd_kernel(cin, cout, hw, N, prelu):
     """conv_igemm_hw4_kernel<..., RED>: the x tile of the BatchNorm-backward reduction is fetched by LDS-DMA behind the loop and
     lands under the output stores; dx stays the plain input gradient bit for bit, the three sums match the stand-alone kernel."""

@@ -19,6 +19,7 @@
 //   fp32 atomics into the (pre-zeroed or accumulating) gradient buffer.
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -126,6 +127,7 @@ int g_conv_bnin = 0;         // "conv_bnin": vlsfr_conv2d_fwd_bnin (BatchNorm / 
                              // 83.2 us (a_out written) fused on the 256-channel layers, 85.0 against 91.0 / 101.0 on the 128-channel ones; the step
                              // 87.0 against 83.5 ms: with ONE wave per SIMD the transform's ~200 extra instructions per k-tile sit in the MFMA wave's own
                              // issue slots, and bn_apply was half hidden beside the other stream's convolutions anyway
+int g_hw4_64 = 1;            // "hw4_64": the 64-channel 3x3 / stride-1 layers on conv_igemm_hw4_kernel<64, 14> (64 x 896 tiles) instead of conv_igemm_halo_kernel
 int g_hw4_red = 1;           // "hw4_red": conv_igemm_hw4_kernel accumulates the BatchNorm-backward reduction in its epilogue when asked to (0: stand-alone kernel)
 int g_hp8_fill = 80;         // "hp8_fill": least percentage of the workgroup slots of its rounds (256 per round) that conv_igemm_hp8_kernel must fill
 int g_tile256_min = 129;     // "tile256_min": the one-round 8-wave tiles are taken from 256 * this many pixels on, i.e. as soon as the 128 x 128 tiling
@@ -1619,14 +1621,17 @@ template <int BM, int NT, int PPW, int DIAG = 0, bool RED = false, int XF = 0>
 __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int PR, int lead) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool TRACE = DIAG == 1;
-  constexpr int BK = 64, NW = 4, WM = BM / 128, WN = NW / WM, MT = 8;
+  // BM = 64 (the 64-channel layers): one wave row of 64 channels, NT = 14 pixel tiles per wave — the same 56 accumulator tiles and
+  // MFMA gaps per step; those layers have ONE 64-channel chunk, so their (large: 896 + 2 W rows) patch is fetched once, in the prologue
+  constexpr int WROWS = BM >= 128 ? 128 : 64;
+  constexpr int BK = 64, NW = 4, WM = BM / WROWS, WN = NW / WM, MT = WROWS / 16;
   constexpr int BN = WN * NT * 16;
   constexpr int RSB = 128;
   constexpr int ASTAGE = BM * RSB;
   constexpr int PA = BM / 8 / NW;            // LDS-DMA pieces of a weight tile per wave (8 rows each): 8 or 4
   constexpr int NMF = MT * NT;               // MFMAs per step
   constexpr int OOB = (int)0x80000000;
-  static_assert((BM == 256 || BM == 128) && NT >= 4 && NT <= 8 && PPW >= 1 && PPW <= 3 && !(XF && RED), "tile");
+  static_assert((BM == 256 || BM == 128 || BM == 64) && MT * NT == 56 && PPW >= 1 && PPW <= 3 && !(XF && RED) && !(XF && BM == 64), "tile");
   constexpr int PT = XF ? 6 : 8;             // taps of a chunk in which pieces of the next patch are fetched
   constexpr int XMP = XF == 2 ? 22 : XF == 1 ? 14 : 0;   // micro-operations of the transform of one piece
   static_assert(XMP * PPW <= 120 && NMF == 56, "the transform of a tap's pieces fits its slots (xf_seq is laid out for 56 gaps per step)");
@@ -1634,7 +1639,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   static_assert((PA + PPW - 1) * DSTEP < NMF && (PA + PPW - 1) * DSTEP + 6 < NMF && PA + PPW + MT + NT + 5 <= NMF && MT + NT + 4 + 2 * NT + 3 * PPW <= NMF, "the side operations of a step fit its MFMA gaps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int PATCH = PR * RSB;
-  const int NPI = PR >> 3;                    // DMA pieces per patch (<= PT * NW * PPW)
+  const int NPI = PR >> 3;                    // DMA pieces per patch (<= PT * NW * PPW where a next patch is fetched in the loop)
+  const int NPATCH = a.C > BK ? 2 : 1;        // patch buffers: double-buffered across chunks, or the one patch of a 64-channel layer
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1774,11 +1780,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   auto stage_p = [&](int x, int cbyte, int pbuf, bool due) {
     const int q = pq + x * 8;
     const int off = (due && (unsigned)q < (unsigned)P) ? pq_off + x * 8 * rowbytes + cbyte : OOB;
-    char* dst = due ? sP + pbuf * PATCH + x * 1024 : sP + 2 * PATCH + 128;
+    char* dst = due ? sP + pbuf * PATCH + x * 1024 : sP + NPATCH * PATCH + 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_void_t*)dst, 16, off, 0, 0, 0);
   };
   for (int x = wave; x < NPI; x += NW) stage_p(x, 0, 0, true);
-  if (tid < 32) ((float*)(sP + 2 * PATCH))[tid] = 0.f;        // the zero row
+  if (tid < 32) ((float*)(sP + NPATCH * PATCH))[tid] = 0.f;   // the zero row
   if (nk > 1)
     for (int e = 0; e < PA; ++e) stage_a1(e, a.C, 1, a_off0);  // k-tile 1 = tap 1 of chunk 0
 
@@ -1820,9 +1826,9 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
 
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
   const uint32_t xk0 = (uint32_t)((h ^ (r16 & 7)) << 4);
-  const uint32_t rowA = lds0 + (uint32_t)((wm * 128 + r16) * RSB) + xk0;      // k-step 0; k-step 1 = ^ 0x40 (the rows are 128-byte aligned)
+  const uint32_t rowA = lds0 + (uint32_t)((wm * WROWS + r16) * RSB) + xk0;      // k-step 0; k-step 1 = ^ 0x40 (the rows are 128-byte aligned)
   const uint32_t ldsP = lds0 + (uint32_t)(2 * ASTAGE);
-  const uint32_t zaddr = ldsP + (uint32_t)(2 * PATCH);
+  const uint32_t zaddr = ldsP + (uint32_t)(NPATCH * PATCH);
   const int rowb0 = lead + wn * (NT * 16) + r16;
 
   // addresses of this lane's NT pixel-tile fragments (k-step 0) for tap (t, tr, ts) of chunk c: the patch row of the neighbour, or
@@ -1836,8 +1842,8 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   int nb_ds = 0, nb_ps = 0;                                  // scalar halves of the next tap's common terms
   auto tap_common_s = [&](int tr, int ts, int c) {
     nb_ds = dsgn * ((tr - 1) * a.W + (ts - 1));             // forward: the neighbour (r - 1, s - 1); input gradient: (1 - r, 1 - s)
-    nb_ps = (int)ldsP + (c & 1) * PATCH - (int)zaddr;
-    asm volatile("" : "+s"(nb_ds), "+s"(nb_ps));
+    nb_ps = (int)ldsP + (c & (NPATCH - 1)) * PATCH - (int)zaddr;   // (one patch buffer: only ever chunk 0, and the last k-tile's idle prefetch stays inside it)
+    nb_ds = (std::remove_reference_t<decltype(nb_ds)>)__builtin_amdgcn_readfirstlane((int)nb_ds); nb_ps = (std::remove_reference_t<decltype(nb_ps)>)__builtin_amdgcn_readfirstlane((int)nb_ps); asm volatile("" : "+s"(nb_ds), "+s"(nb_ps));
   };
   auto tap_common_v = [&](int t) {
     const int rowb = rowb0 + nb_ds;
@@ -1913,7 +1919,7 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   int t = 0, c = 0, tn = 1, trn = 0, tsn = 1, cn = 0;
   uint32_t sb = 0;
   int k2s = 0, a_voff = OOB;
-  const uint32_t dump = (uint32_t)(uintptr_t)(lds_void_t*)(sP + 2 * PATCH + 128);
+  const uint32_t dump = (uint32_t)(uintptr_t)(lds_void_t*)(sP + NPATCH * PATCH + 128);
   uint32_t p_dst[PPW];
   int p_soff[PPW];
   int p_q8[PPW];                 // XF: first row of the piece relative to the patch (far out of range when no piece is due)
@@ -1960,11 +1966,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
         const int wrap = t + 2 >= 9;
         s_tmp0 = (wrap ? t - 7 : t + 2) * a.C;
         s_tmp1 = (c + wrap) * BK;
-        asm volatile("" : "+s"(s_tmp0), "+s"(s_tmp1));
+        s_tmp0 = (std::remove_reference_t<decltype(s_tmp0)>)__builtin_amdgcn_readfirstlane((int)s_tmp0); s_tmp1 = (std::remove_reference_t<decltype(s_tmp1)>)__builtin_amdgcn_readfirstlane((int)s_tmp1); asm volatile("" : "+s"(s_tmp0), "+s"(s_tmp1));
       } else if constexpr (n == G + 3 + 2 * NT) {
         k2s = (s_tmp0 + s_tmp1) * 2;
         a_voff = ((int)(u + 2 < nk) & (int)dma) ? a_off0 : OOB;
-        asm volatile("" : "+s"(k2s), "+v"(a_voff));
+        k2s = (std::remove_reference_t<decltype(k2s)>)__builtin_amdgcn_readfirstlane((int)k2s); asm volatile("" : "+s"(k2s), "+v"(a_voff));
       } else if constexpr (n >= G + 4 + 2 * NT && n < G + 4 + 2 * NT + 3 * PPW) {   // this tap's piece(s) of the next chunk's patch, three gaps each
         constexpr int e = (n - (G + 4 + 2 * NT)) / 3, part = (n - (G + 4 + 2 * NT)) % 3;
         if constexpr (part == 0) {
@@ -1976,10 +1982,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
           s_px = (t * NW + wave) * PPW + e;
           s_due = -((int)dma & (int)(t < PT) & (int)(c + 1 < nchunk) & (int)(s_px < NPI));      // all ones / zero (no branch)
           if constexpr (XF != 0) p_q8[e] = (s_px * 8 & s_due) | (-(1 << 28) & ~s_due);
-          asm volatile("" : "+s"(s_px), "+s"(s_due));
+          s_px = (std::remove_reference_t<decltype(s_px)>)__builtin_amdgcn_readfirstlane((int)s_px); s_due = (std::remove_reference_t<decltype(s_due)>)__builtin_amdgcn_readfirstlane((int)s_due); asm volatile("" : "+s"(s_px), "+s"(s_due));
         } else if constexpr (part == 1) {
           p_dst[e] = dump + ((ldsP + (uint32_t)(((c + 1) & 1) * PATCH + s_px * 1024) - dump) & (uint32_t)s_due);
-          asm volatile("" : "+s"(p_dst[e]));
+          p_dst[e] = (std::remove_reference_t<decltype(p_dst[e])>)__builtin_amdgcn_readfirstlane((int)p_dst[e]); asm volatile("" : "+s"(p_dst[e]));
         } else {
           p_soff[e] = s_px * 8 * rowbytes + (c + 1) * (BK * 2);
           // (no pin here: with the a_out store of the transform the compiler derives this sum from a per-lane one, and an "s" constraint then asks for an illegal VGPR -> SGPR copy)
@@ -2049,26 +2055,26 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
         t = tn;
         c = cn;
         sb ^= (uint32_t)ASTAGE;
-        asm volatile("" : "+s"(t), "+s"(c), "+s"(sb));
+        t = (std::remove_reference_t<decltype(t)>)__builtin_amdgcn_readfirstlane((int)t); c = (std::remove_reference_t<decltype(c)>)__builtin_amdgcn_readfirstlane((int)c); sb = (std::remove_reference_t<decltype(sb)>)__builtin_amdgcn_readfirstlane((int)sb); asm volatile("" : "+s"(t), "+s"(c), "+s"(sb));
       } else if constexpr (n == ADV + 1) {
         ++tn;
         ++tsn;
-        asm volatile("" : "+s"(tn), "+s"(tsn));
+        tn = (std::remove_reference_t<decltype(tn)>)__builtin_amdgcn_readfirstlane((int)tn); tsn = (std::remove_reference_t<decltype(tsn)>)__builtin_amdgcn_readfirstlane((int)tsn); asm volatile("" : "+s"(tn), "+s"(tsn));
       } else if constexpr (n == ADV + 2) {
         const int w3 = tsn == 3;
         tsn = w3 ? 0 : tsn;
         trn += w3;
-        asm volatile("" : "+s"(tsn), "+s"(trn));
+        tsn = (std::remove_reference_t<decltype(tsn)>)__builtin_amdgcn_readfirstlane((int)tsn); trn = (std::remove_reference_t<decltype(trn)>)__builtin_amdgcn_readfirstlane((int)trn); asm volatile("" : "+s"(tsn), "+s"(trn));
       } else if constexpr (n == ADV + 3) {
         const int w9 = tn == 9;
         cn += w9;
         tn = w9 ? 0 : tn;
-        asm volatile("" : "+s"(tn), "+s"(cn));
+        tn = (std::remove_reference_t<decltype(tn)>)__builtin_amdgcn_readfirstlane((int)tn); cn = (std::remove_reference_t<decltype(cn)>)__builtin_amdgcn_readfirstlane((int)cn); asm volatile("" : "+s"(tn), "+s"(cn));
       } else if constexpr (n == ADV + 4) {
         const int z = tn == 0;                             // (tap 0 is only ever reached by the wrap)
         trn = z ? 0 : trn;
         tsn = z ? 0 : tsn;
-        asm volatile("" : "+s"(tsn), "+s"(trn));
+        tsn = (std::remove_reference_t<decltype(tsn)>)__builtin_amdgcn_readfirstlane((int)tsn); trn = (std::remove_reference_t<decltype(trn)>)__builtin_amdgcn_readfirstlane((int)trn); asm volatile("" : "+s"(tsn), "+s"(trn));
       } else if constexpr (XF != 0 && n == ADV + 5) {
         if (t == 0) xf_load(c + 1);                        // a chunk begins: the constants of the patch fetched during it (first used in tap 2)
       }
@@ -2083,11 +2089,11 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (a.dbg & 64) {                             // diagnostic: no epilogue
-    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0] + acc[3][NT - 1][3] + acc[1][2][1] + acc[7][5][2];
+    if (acc[0][0][0] == 12345.678f) ((float*)a.y)[tid] = acc[0][0][0] + acc[3][NT - 1][3] + acc[1][2][1] + acc[MT - 1][5][2];
     return;
   }
   if constexpr (RED) {
-    static_assert(BN * BM * 2 <= 2 * BM * 128 + 2 * BN * 128, "the x tile fits the LDS this kernel always has (two weight buffers, two patches of >= BN rows)");
+    static_assert(BN * BM * 2 <= 160 * 1024, "the x tile fits LDS (launch_igemm_hw4 sizes the allocation for it)");
     constexpr int XRB = BM * 2, XCPR = XRB / 16, XRPI = 1024 / XRB, XI = BN / XRPI / NW;
     static_assert(BN % (XRPI * NW) == 0, "x tile pieces divide over the waves");
     const __amdgpu_buffer_rsrc_t rs_rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.red_x, 0, (int)((size_t)P * a.Mrows * 2), 0x00020000);
@@ -2828,7 +2834,7 @@ int launch_igemm_p8(const ConvArgs& a, int P, hipStream_t st) {
 // LDS of conv_igemm_hp8_kernel: two weight buffers, two patches, the zero row.  lead = halo rows in front of the tile's first pixel
 inline int hp8_lead(int BN, int W) { return BN % W == 0 ? W : W + 1; }
 inline int hp8_patch_rows(int BN, int W) { return (BN + 2 * hp8_lead(BN, W) + 7) & ~7; }
-inline int hp8_lds_bytes(int BM, int BN, int W) { return 2 * BM * 128 + 2 * hp8_patch_rows(BN, W) * 128 + 128; }
+inline int hp8_lds_bytes(int BM, int BN, int W, int npatch = 2) { return 2 * BM * 128 + npatch * hp8_patch_rows(BN, W) * 128 + 128; }
 
 template <int BM, int NT>
 int launch_igemm_hp8(const ConvArgs& a, int P, hipStream_t st) {
@@ -2850,9 +2856,24 @@ int launch_igemm_hp8(const ConvArgs& a, int P, hipStream_t st) {
 
 template <int BM, int NT>
 int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
-  constexpr int BN = (4 / (BM / 128)) * NT * 16;
+  constexpr int WROWS = BM >= 128 ? 128 : 64;
+  constexpr int BN = (4 / (BM / WROWS)) * NT * 16;
   const int lead = hp8_lead(BN, a.W), PR = hp8_patch_rows(BN, a.W);
-  const int lds = hp8_lds_bytes(BM, BN, a.W) + 1024;   // + the dump area of the LDS-DMA pieces that have nothing to fetch
+  int lds = hp8_lds_bytes(BM, BN, a.W, a.C > 64 ? 2 : 1) + 1024;   // + the dump area of the LDS-DMA pieces that have nothing to fetch
+  if (red && lds < BN * BM * 2) lds = BN * BM * 2;                 // (the x tile of the fused reduction reuses the loop's LDS from offset 0)
+  if constexpr (BM == 64) {
+    auto kern64 = red ? conv_igemm_hw4_kernel<64, 14, 1, 0, true> : conv_igemm_hw4_kernel<64, 14, 1, 0, false>;
+    if (int rc = ensure_dynamic_lds((const void*)kern64, lds, "conv_igemm_hw4")) return rc;
+    dim3 grid((P + BN - 1) / BN, a.Mrows / BM, 1);
+    ConvArgs b = a;
+    const size_t nwg = (size_t)grid.x * grid.y;
+    b.gx = (int)grid.x;
+    b.gy = (int)grid.y;
+    b.xcd = g_xcd_map && nwg >= 16 && nwg < (1u << 30);
+    if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
+    hipLaunchKernelGGL(kern64, grid, dim3(256), lds, st, b, PR, lead);
+    return VLSFR_OK;
+  } else {
   // pieces of the next patch per wave and tap: 8 x 4 x PPW slots per chunk, 6 x 4 x PPW with the input transform (XF)
   constexpr int XPPW = BM == 256 ? 2 : 3;
   if (a.xf_scale && PR / 8 > 24 * XPPW) return fail(VLSFR_EINVAL, "conv_igemm_hw4: patch of %d rows does not fit the transform's piece slots", PR);
@@ -2870,6 +2891,7 @@ int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
   if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b, PR, lead);
   return VLSFR_OK;
+  }
 }
 
 template <int BM, int PI>
@@ -2895,11 +2917,17 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
 // 128-row tiles x 448 pixels, where those tiles fill at least g_hp8_fill % of the workgroup slots of their rounds
 int hp8_tile_rows(int Mrows, int C, int H, int W, int Ho, int Wo, int R, int S, int stride, int pad, int P) {
   if (!g_conv_hp8 || !(R == 3 && S == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && H >= 2 && C % 64 == 0)) return 0;
-  const int bm = (Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (Mrows == 128 && g_conv_hp8 != 2) ? 128 : 0;
+  // (64 rows: the 64-channel layers, one chunk, one-wave-per-SIMD kernel only — "hw4_64")
+  const int bm = (Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (Mrows == 128 && g_conv_hp8 != 2) ? 128
+                 : (Mrows == 64 && C == 64 && g_conv_hw4 && g_hw4_64 && g_conv_hp8 == 1) ? 64 : 0;
   if (!bm) return 0;
-  const int bn = bm == 256 ? 224 : 448;
+  const int bn = bm == 256 ? 224 : bm == 128 ? 448 : 896;
   const long tiles = (long)((P + bn - 1) / bn) * (Mrows / bm), rounds = (tiles + 255) / 256;
-  if (hp8_lds_bytes(bm, bn, W) + 1024 <= 160 * 1024 && hp8_patch_rows(bn, W) <= 512 && tiles * 100 >= rounds * 256 * g_hp8_fill) return bm;
+  const int npatch = C > 64 ? 2 : 1;
+  // (64-row tiles: nine k-tiles per tile, so a tile is mostly its patch fetch and its stores; measured at batch 256 they win where
+  // there are many rounds of them — 112 x 112: 525 -> 385 us forward, 14 rounds — and not at 56 x 56: 98 -> 100 us, 3.5 rounds)
+  if (bm == 64 && g_hp8_fill > 0 && tiles < 8 * 256) return 0;
+  if (hp8_lds_bytes(bm, bn, W, npatch) + 1024 <= 160 * 1024 && (bm == 64 || hp8_patch_rows(bn, W) <= 512) && tiles * 100 >= rounds * 256 * g_hp8_fill) return bm;
   return 0;
 }
 
@@ -2936,28 +2964,31 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
   // layers, 448 on the 128-channel 28 x 28 layers).  A launch that wants the fused BatchNorm-backward reduction takes the
   // stand-alone reduction kernel instead (red_done stays false), as with the one-round tiles below.
   int hp8_bm = 0;
-  if (glds_ok && !halo_ok && variant_default && !a.tap_mask && a.splitk == 1 && !a.out_f32 && !(g_bnred_all && !(g_conv_hw4 && g_hw4_red)))
+  if (glds_ok && variant_default && !a.tap_mask && a.splitk == 1 && !a.out_f32 && !(g_bnred_all && !(g_conv_hw4 && g_hw4_red)))
     hp8_bm = hp8_tile_rows(a.Mrows, a.C, a.H, a.W, a.Ho, a.Wo, a.R, a.S, a.stride, a.pad, P);
+  if (hp8_bm != 64 && halo_ok) hp8_bm = 0;     // (the 64-row tiles replace conv_igemm_halo_kernel; everything else it still takes keeps it)
+  const bool halo_here = halo_ok && !hp8_bm;
   if (a.xf_scale && !(hp8_bm && g_conv_hw4))
     return fail(VLSFR_EINVAL, "conv_igemm: the fused input BatchNorm needs conv_igemm_hw4_kernel (vlsfr_conv2d_fwd_bnin_supported)");
   // (one round of one tile per CU: the tile count over BOTH grid dimensions is bounded by the 256 CUs — 512 output channels at
   // >= 33 024 pixels would be two rounds, the case the 128 x 128 tiles win)
-  const bool tile256_here = !hp8_bm && glds_ok && !halo_ok && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
+  const bool tile256_here = !hp8_bm && glds_ok && !halo_here && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
                             (long)(a.Mrows / 256) * ((P + 255) / 256) <= 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
-  const bool red_here = !hp8_bm && glds_ok && !halo_ok && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
+  const bool red_here = !hp8_bm && glds_ok && !halo_here && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
                         (size_t)(a.cls ? a.Nimg * a.Hf * a.Wf : P) * a.Mrows < (1ull << 30) && (g_bnred_all || (big_tile && !a.cls));
   // the one-wave-per-SIMD kernel carries the reduction itself ("hw4_red", default on): x tile fetched behind the loop
   const bool hw4_red = hp8_bm && g_conv_hw4 && g_hw4_red && a.red_x && !a.cls &&
                        (size_t)P * a.Mrows < (1ull << 30);
   ProfScope prof(st, (red_here || hw4_red) ? 3 : 0, alg_flops);
-  if (halo_ok) {
+  if (halo_here) {
     int rc;
     const bool pi2 = (128 + 2 * a.W + 2 + 7) / 8 > 32;
     if (a.Mrows >= 128) rc = pi2 ? launch_igemm_halo<128, 2>(a, P, st) : launch_igemm_halo<128, 1>(a, P, st);
     else rc = pi2 ? launch_igemm_halo<64, 2>(a, P, st) : launch_igemm_halo<64, 1>(a, P, st);
     if (rc != VLSFR_OK) return rc;
   } else if (hp8_bm) {
-    const int rc = g_conv_hw4 ? (hp8_bm == 256 ? launch_igemm_hw4<256, 7>(a, P, st, hw4_red) : launch_igemm_hw4<128, 7>(a, P, st, hw4_red))
+    const int rc = hp8_bm == 64 ? launch_igemm_hw4<64, 14>(a, P, st, hw4_red)
+                   : g_conv_hw4 ? (hp8_bm == 256 ? launch_igemm_hw4<256, 7>(a, P, st, hw4_red) : launch_igemm_hw4<128, 7>(a, P, st, hw4_red))
                               : (hp8_bm == 256 ? launch_igemm_hp8<256, 7>(a, P, st) : launch_igemm_hp8<128, 7>(a, P, st));
     if (hw4_red && red_done) *red_done = true;
     if (rc != VLSFR_OK) return rc;
@@ -3100,6 +3131,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "conv_bnin")) {
     g_conv_bnin = value;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "hw4_64")) {
+    g_hw4_64 = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "hw4_red")) {
