@@ -123,8 +123,8 @@ int g_conv_hp8 = 1;          // "conv_hp8": the halo-patch four-phase kernel (co
                              // 1 = 256-row and 128-row tiles (default), 2 = 256-row tiles only, 3 = 128-row tiles only, 0 = off
 int g_conv_hw4 = 1;          // "conv_hw4": the one-wave-per-SIMD software-pipelined form of that kernel (conv_igemm_hw4_kernel) where conv_hp8 applies
 int g_conv_bnin = 0;         // "conv_bnin": vlsfr_conv2d_fwd_bnin (BatchNorm / PReLU of the input applied in conv_igemm_hw4_kernel's operand path) offered to the
-                             // executors.  OFF by default — measured (scripts/bnin_micro.py, batch 256): bn_apply + conv 72.5 us against 73.0 (no a_out) /
-                             // 83.2 us (a_out written) fused on the 256-channel layers, 85.0 against 91.0 / 101.0 on the 128-channel ones; the step
+                             // executors.  OFF by default — measured (scripts/bnin_micro.py, batch 256): bn_apply + conv 71.1 us against 70.4 (no a_out) /
+                             // 79.5 us (a_out written) fused on the 256-channel layers, 84.9 against 92.4 / 102.1 on the 128-channel ones; the step
                              // 87.0 against 83.5 ms: with ONE wave per SIMD the transform's ~200 extra instructions per k-tile sit in the MFMA wave's own
                              // issue slots, and bn_apply was half hidden beside the other stream's convolutions anyway
 int g_hw4_64 = 1;            // "hw4_64": the 64-channel 3x3 / stride-1 layers on conv_igemm_hw4_kernel<64, 14> (64 x 896 tiles) instead of conv_igemm_halo_kernel
@@ -1575,13 +1575,6 @@ constexpr int xf_seq(int step, int n) {
   return step == 0 ? (n <= 14 ? n : (n >= 37 && n <= 55 ? 15 + (n - 37) : -1)) : (n >= 27 && n <= 52 ? 34 + (n - 27) : -1);
 }
 
-// MFMA with the accumulator pinned in the accumulator half of the register file ("+a"): with 224 accumulator registers and a
-// 120-register fragment double buffer per wave the compiler otherwise shuttles accumulator tiles between the two halves every
-// iteration (hundreds of v_accvgpr moves per k-tile).  Inline asm also fixes the instruction's place in the stream.
-__device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-}
-
 // ------------------------------------------------------------------------------------------------
 // conv_igemm_hw4_kernel -- the same halo-patch operand path with ONE WAVE PER SIMD and a single software-pipelined instruction
 // stream instead of two waves per SIMD trading places at barriers.  What the stamps of conv_igemm_hp8_kernel showed
@@ -1996,10 +1989,10 @@ __global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int 
     });
 
     // ---- step 2u + 1 (k = 32..63, fragments F[1]); the k-tile's barrier; DMA of k-tile u + 2 and of the patch piece; reads of step 2u + 2
-    // (XF: the PPW a_out stores of the step just finished are the youngest vector-memory operations and stay in flight — a store's
-    // acknowledgement takes longer than a k-tile; everything older, i.e. the DMA and the constants' loads, is drained)
-    if constexpr (XF != 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // (XF: the a_out stores of the transform count in vmcnt too and are interleaved with the DMA pieces in issue order — some of
+    // the transform's slots lie in the second step — so no counted wait can leave "only the stores" in flight: everything is drained,
+    // store acknowledgements included.  A first version that left PPW operations in flight raced with the last DMA pieces.)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if constexpr (TRACE) {
       if (tr_on && u < 64) {

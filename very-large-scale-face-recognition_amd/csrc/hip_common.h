@@ -22,6 +22,19 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// The same MFMA with the accumulator pinned in the accumulator half of the register file ("+a") and the instruction's place in the
+// stream fixed (asm volatile): for kernels whose accumulators (224 - 256 registers per wave) only fit there — left to the compiler
+// they are shuttled between the two halves every iteration or spilled.  The compiler's hazard recogniser does not see an MFMA in
+// it: a reader of `c` other than the next MFMA on it must be kept away by s_nops (conv_igemm_hw4_kernel's epilogue).
+__device__ __forceinline__ void mfma16_agpr(f32x4& c, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+// ... and with the accumulator in architectural VGPRs ("+v"): the small product of a kernel whose accumulator file is full
+__device__ __forceinline__ void mfma16_vgpr(f32x4& c, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+
 // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements is delivered
 // column-major — lane i of the group receives column i, rows 0..3.  Lane 4q + p of the group
 // supplies the LDS address of row q, columns 4p..4p+3 (8-byte aligned).
