@@ -1103,6 +1103,7 @@ int round_dp(int D) {
 }
 
 int g_head_variant = -1;   // "head_variant": bf16-shadow sweep geometry (head_sweep16.h); -1 = by batch size
+int g_head_dma_spread = 0; // "head_dma_spread": Sweep16Args::dma_spread
 
 struct Plan {
   bool fast;   // shadow sweep: bf16 (head16.hip, variants 0 / 1) or fp8 (head8.hip, variant 2)
@@ -1334,6 +1335,7 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
       f.Bp = a.Bp;
       f.n_rowblk = a.n_rowblk;
       f.slot_lo = a.slot_lo;
+      f.dma_spread = g_head_dma_spread;
       rc = launch_sweep16(f, pl.variant, topk, sv, st);
     } else {
       rc = cfg->precise ? dispatch_sweep<true>(pl.DP, a, topk, sv, grid, st) : dispatch_sweep<false>(pl.DP, a, topk, sv, grid, st);
@@ -1353,6 +1355,10 @@ int run_sweeps(const vlsfr_head_cfg* cfg, const Plan& pl, SweepArgs a, char* ws,
 
 namespace vlsfr {
 int head_set_option(const char* name, int32_t value) {
+  if (!strcmp(name, "head_dma_spread")) {
+    g_head_dma_spread = value != 0;
+    return 0;
+  }
   if (!strcmp(name, "head_variant")) {
     if (value < -1 || value > 1) return fail(VLSFR_EINVAL, "head_variant must be -1 (auto), 0 or 1");
     g_head_variant = value;

@@ -185,6 +185,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void head_sweep16_kernel(Sweep16Ar
     for (int i = 0; i < DR; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(st + i * ROWB), 16, voff, soff + i * (DP * 2), 0, 0);
   };
+  auto issue_one = [&](int t, int i) {
+    char* st = smem + (t % NS) * TILE_B + wave * DR * ROWB;
+    const int soff = (t * TQ + wave * DR) * (DP * 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(st + i * ROWB), 16, voff, soff + i * (DP * 2), 0, 0);
+  };
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t*)smem;
   const uint32_t bits0 = lds0 + NS * TILE_B;
   const uint32_t off1 = (uint32_t)(r16 * ROWB + h * 16);                      // row reads: row r16 (+16 jb), chunk 4 ks + h
@@ -196,7 +201,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void head_sweep16_kernel(Sweep16Ar
   for (int t = 0; t < ntiles; ++t) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * DR) : "memory");   // this wave's rows of tile t have landed
     __builtin_amdgcn_s_barrier();                                           // everybody's; and tile t - 1 is no longer read
-    issue(t + NS - 1);                                                      // into the slot of tile t - 1
+    // the DR LDS-DMA pieces of tile t + NS - 1 (into the slot of tile t - 1): all at once behind the barrier, or ("head_dma_spread",
+    // round 4) one every SPREAD_EVERY k-steps of the first product — issued together the 8 waves queue 32 pieces on the CU's one
+    // address path right when every wave also starts its fragment reads
+    const bool spread = a.dma_spread && wave_active;
+    if (!spread) issue(t + NS - 1);
     if (wave_active) {
       // register classes, stated once per tile: the O accumulators own the accumulator file, the P fragments
       // stay in architectural VGPRs (left to itself the allocator spills P and reloads it every k-step at RB = 2)
@@ -226,6 +235,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void head_sweep16_kernel(Sweep16Ar
       });
       static_for<KS>([&](auto I) {
         constexpr int ks = decltype(I)::value;
+        if constexpr (ks % (KS / DR) == 0 && ks / (KS / DR) < DR) {
+          if (spread) issue_one(t + NS - 1, ks / (KS / DR));
+        }
         if constexpr (ks + PF1 < KS) {
           constexpr int kn = ks + PF1;
           wa[kn % (PF1 + 1)][0] = lds_r128<kn * 64>(a1);

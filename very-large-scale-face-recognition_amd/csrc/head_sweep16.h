@@ -34,6 +34,7 @@ struct Sweep16Args {
   int32_t Bp;                // n_rowblk * rows per workgroup
   int32_t n_rowblk;
   int32_t slot_lo;
+  int32_t dma_spread = 0;    // 1: the LDS-DMA pieces of a tile are issued one by one inside the first product ("head_dma_spread")
 };
 
 // variant 0: 4 waves x 16 rows (64 probe rows per workgroup, one wave per SIMD) — batch <= 64, HBM-bound;
