@@ -16,7 +16,7 @@ SHAPES = [(64, 64, 3, 1, 112, 1), (64, 64, 3, 2, 112, 1), (64, 64, 1, 2, 112, 1)
 if os.environ.get("ONLY"):
     keep = set(os.environ["ONLY"].split())
     SHAPES = [sh for sh in SHAPES if "%d_%d_%d_%d_%d" % sh[:5] in keep]
-def timeit(fn, n=10):
+def timeit(fn, n=int(os.environ.get('ITERS', 10))):
     for _ in range(2): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
@@ -36,6 +36,7 @@ for cin, cout, k, stride, h, cnt in SHAPES:
     stats = ops.new_sums(cout, "cuda")
     fl = 2.0 * B * ho * ho * cout * k * k * cin
     tf = timeit(lambda: ops.conv2d_fwd(x, w, d, stats=None if os.environ.get("NOSTATS") else stats))
+    if os.environ.get('BOTH'): print('   forward without statistics %.1f us' % (timeit(lambda: ops.conv2d_fwd(x, w, d, stats=None)) * 1e6))
     td = timeit(lambda: ops.conv2d_dgrad(dy, wT, d))
     tw = timeit(lambda: ops.conv2d_wgrad_ws(dy, x, d, dw=dw)) if os.environ.get("WS") else timeit(lambda: ops.conv2d_wgrad(dy, x, d, dw=dw))
     ms = cnt * (4 * tf + 2 * td + 2 * tw) * 1e3

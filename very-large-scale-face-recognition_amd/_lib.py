@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint8, c_void_p, c_size_t
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlsfr.so")
+# (VLSFR_LIB: another build of the same library, for A/B runs of compile-time choices; the default is the in-tree build)
+LIB_PATH = os.environ.get("VLSFR_LIB") or os.path.join(_HERE, "libvlsfr.so")
 
 
 class VlsfrError(RuntimeError):

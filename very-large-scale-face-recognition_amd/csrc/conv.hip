@@ -407,24 +407,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     }
     return;
   }
-  // bf16 output; the BatchNorm statistics are taken from the ROUNDED values (what the consumer reads), as sums of
-  // DEVIATIONS from a pivot: the value of the first pixel of this wave's pixel range for the channel (lane r16 = 0 of the
-  // 16-lane row holds it; one ds_bpermute per channel hands it to the row).  Deviations are of the order of the spread
-  // whatever the mean, so fp32 is enough up to the workgroup level; (sum x, sum x^2) are formed and added in float64 there.
-  float cs[MT][4], cq[MT][4], cp[MT][4];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) cs[i][e] = cq[i][e] = cp[i][e] = 0.f;
-  if constexpr (!RED) {
-    if (a.stats) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) cp[i][e] = __shfl((float)(__bf16)acc[i][0][e], (tid & 63) & 48, 64);
-    }
-  }
-  // 16-byte stores: rows h and h ^ 1 of the MFMA layout hold channels 4h..4h+3 and 4h+4..4h+7 of the same
+  // bf16 output.  16-byte stores: rows h and h ^ 1 of the MFMA layout hold channels 4h..4h+3 and 4h+4..4h+7 of the same
   // pixel, so v_permlane16_swap hands the even rows both halves of pixel tile j and the odd rows both
   // halves of tile j + 1 -- 8 dwordx4 stores per lane instead of 16 dwordx2 (the store tail of a workgroup
   // is issue-bound, not bandwidth-bound).
@@ -458,42 +441,43 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
 #pragma unroll
     for (int jp = 0; jp < NT / 2; ++jp) orow[jp] = pw + (2 * jp + (odd ? 1 : 0)) * 16;
   }
+  const int Pst = (a.dbg & 512) ? 0 : P;        // diagnostic 512: every output store masked off
+  if (a.dbg & 1024) {                           // diagnostic 1024: every workgroup stores to the first 256 rows (cache-resident lines)
+#pragma unroll
+    for (int jp = 0; jp < NT / 2; ++jp) orow[jp] &= 255;
+  }
   u16* ybase = (u16*)a.y + (mw - 4 * (h & 1));
+  // Phase 1 — round, pair, store: every output store of the wave is issued before any of the statistics' arithmetic, so the
+  // stores drain (all workgroups of a round write at the same time: the drain is bandwidth-bound) UNDER that arithmetic instead
+  // of behind it.  pk[i][j] = the four rounded values of tile (i, j) as two packed pairs (channels e = 0, 1 | 2, 3): what the
+  // statistics and the fused reduction below read, so that they see exactly what the consumer will.
+  uint32_t pk[MT][NT][2];
   auto store = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int jp = 0; jp < NT / 2; ++jp) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        uint32_t w[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const int j = 2 * jp + t;
-          const bool ok = FULL || (pw + j * 16 < P && mw + i * 16 < a.Mrows);
           bf16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = (__bf16)acc[i][j][e];
-            if constexpr (!RED) {   // forward statistics (an input-gradient launch with the fused reduction has none)
-              const float f = ok ? (float)o[e] - cp[i][e] : 0.f;
-              cs[i][e] += f;
-              cq[i][e] += f * f;
-            }
-          }
+          for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
           const uint2 u = __builtin_bit_cast(uint2, o);
-          w[t][0] = u.x;
-          w[t][1] = u.y;
+          pk[i][j][0] = u.x;
+          pk[i][j][1] = u.y;
         }
-        const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[i][2 * jp][0], pk[i][2 * jp + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[i][2 * jp][1], pk[i][2 * jp + 1][1], false, false);
         const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         const int j = 2 * jp + (odd ? 1 : 0);
-        const bool okst = FULL || (pw + j * 16 < P && mw - 4 * (h & 1) + i * 16 < a.Mrows);
+        const bool okst = FULL || (pw + j * 16 < Pst && mw - 4 * (h & 1) + i * 16 < a.Mrows);
         if (okst) *(uint4*)(ybase + (size_t)orow[jp] * a.Mrows + i * 16) = v;
       }
     }
   };
-  const bool full_tile = p0 + BN <= P && m0 + BM <= a.Mrows;
+  const bool full_tile = p0 + BN <= Pst && m0 + BM <= a.Mrows;
   if (full_tile) store(std::true_type{});
   else store(std::false_type{});
   if constexpr (NT % 2 == 1) {   // the unpaired last pixel tile (never a parity-class launch: run_igemm)
@@ -504,26 +488,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
       const bool ok = pok && (full_tile || mw + i * 16 < a.Mrows);
       bf16x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = (__bf16)acc[i][j][e];
-        if constexpr (!RED) {
-          const float f = ok ? (float)o[e] - cp[i][e] : 0.f;
-          cs[i][e] += f;
-          cq[i][e] += f * f;
-        }
-      }
-      if (ok) *(uint2*)((u16*)a.y + (size_t)(pw + j * 16) * a.Mrows + mw + i * 16) = __builtin_bit_cast(uint2, o);
+      for (int e = 0; e < 4; ++e) o[e] = (__bf16)acc[i][j][e];
+      const uint2 u = __builtin_bit_cast(uint2, o);
+      pk[i][j][0] = u.x;
+      pk[i][j][1] = u.y;
+      if (ok && pw + j * 16 < Pst) *(uint2*)((u16*)a.y + (size_t)((a.dbg & 1024) ? ((pw + j * 16) & 255) : pw + j * 16) * a.Mrows + mw + i * 16) = u;
     }
   }
+  __builtin_amdgcn_sched_barrier(0);   // (phase 2 stays behind the last store)
+  // rounded value e of tile (i, j) as a float
+  auto rounded = [&](int i, int j, int e) __attribute__((always_inline)) {
+    const uint32_t wd = pk[i][j][e >> 1];
+    return __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+  };
   // Per-channel sums -> one of VLSFR_BN_REPL replicated accumulators out[rep][q][Mrows].  A lane's partial for channel
   // 16 i + 4 h + e (of this wave's channel range) is summed over the 16 pixel lanes of its row with DPP adds (no LDS round
-  // trips) and kept by lane r16 = 4 (i & 3) + e; the WN pixel halves of the workgroup meet in the LDS stage the last k-tile
+  // trips; row16_fold16) and kept by lane r16 = 4 (i & 3) + e; the WN pixel halves of the workgroup meet in the LDS stage the last k-tile
   // did not use (its readers all passed the last barrier), then ONE global atomic per channel, quantity and workgroup.
   constexpr int NR = (MT + 3) / 4;   // rounds of 16 (i, e) values: one value per pixel lane of the row
-  auto fold = [&](float t, int i, int e, float (&keep)[NR]) {
-    t = row16_sum(t);
-    if (r16 == (i & 3) * 4 + e) keep[i >> 2] = t;
-  };
   auto flush = [&](auto nq_tag, float (&keep)[decltype(nq_tag)::value][NR], float* out) {
     constexpr int NQ = decltype(nq_tag)::value;
     float* red = red_lds;   // [WN][NQ][BM]
@@ -546,18 +528,60 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
       if (m0 + ml < a.Mrows) atomicAdd(dst + (size_t)k * a.Mrows + m0 + ml, t);
     }
   };
-  if (a.stats) {   // fused BatchNorm statistics of the rounded output (forward launches)
+  if (!RED && a.stats) {   // Phase 2 — fused BatchNorm statistics of the rounded output (forward launches)
+    // The statistics are taken from the ROUNDED values (what the consumer reads), as sums of DEVIATIONS from a pivot: the value of
+    // the first pixel of this wave's pixel range for the channel (lane r16 = 0 of the 16-lane row holds it; one ds_bpermute per
+    // channel hands it to the row).  Deviations are of the order of the spread whatever the mean, so fp32 is enough up to the
+    // workgroup level; (sum x, sum x^2) are formed and added in float64 there.  One channel tile i at a time (pixel tiles in
+    // ascending order, as ever: the same sums bit for bit), folded over the row's 16 pixel lanes as soon as it is complete.
     float keep[3][NR];   // sum of deviations, sum of squared deviations, pivot
 #pragma unroll
     for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = keep[2][r] = 0.f;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // (a round = four channel tiles = the 16 (i & 3, e) values of one lane; row16_fold16 leaves the row sum of value k with lane r16 = k)
+    auto round_stats = [&](auto rc, auto full_tag) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      constexpr bool FULL = decltype(full_tag)::value;
+      float S[16], Q[16], PV[16];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int k = 0; k < 16; ++k) S[k] = Q[k] = PV[k] = 0.f;
+      static_for<(MT - 4 * r < 4 ? MT - 4 * r : 4)>([&](auto iic) {
+        constexpr int ii = decltype(iic)::value, i = 4 * r + ii;
+        f32x2 cp2[2], cs2[2], cq2[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        fold(cs[i][e], i, e, keep[0]);
-        fold(cq[i][e], i, e, keep[1]);
-        if (r16 == (i & 3) * 4 + e) keep[2][i >> 2] = cp[i][e];   // the row shares one pivot: no sum
-      }
+        for (int g = 0; g < 2; ++g) {
+          cp2[g][0] = __shfl(rounded(i, 0, 2 * g), (tid & 63) & 48, 64);
+          cp2[g][1] = __shfl(rounded(i, 0, 2 * g + 1), (tid & 63) & 48, 64);
+          cs2[g] = (f32x2){0.f, 0.f};
+          cq2[g] = (f32x2){0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bool ok = FULL || (pw + j * 16 < P && mw + i * 16 < a.Mrows);
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            f32x2 f = (f32x2){rounded(i, j, 2 * g), rounded(i, j, 2 * g + 1)} - cp2[g];
+            if (!ok) f = (f32x2){0.f, 0.f};
+            cs2[g] += f;
+            cq2[g] += f * f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          S[ii * 4 + e] = cs2[e >> 1][e & 1];
+          Q[ii * 4 + e] = cq2[e >> 1][e & 1];
+          PV[ii * 4 + e] = cp2[e >> 1][e & 1];
+        }
+      });
+      keep[0][r] = row16_fold16(S, r16);
+      keep[1][r] = row16_fold16(Q, r16);
+      float pv = 0.f;   // the row shares one pivot: no sum
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pv = r16 == k ? PV[k] : pv;
+      keep[2][r] = pv;
+    };
+    if (full_tile) static_for<NR>([&](auto rc) { round_stats(rc, std::true_type{}); });
+    else static_for<NR>([&](auto rc) { round_stats(rc, std::false_type{}); });
     float* red = red_lds;   // [WN][3][BM]
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
@@ -605,63 +629,92 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
     float keep[3][NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) keep[0][r] = keep[1][r] = keep[2][r] = 0.f;
-    if (!(a.dbg & 8))
-    static_for<MT>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const int mc = mw + i * 16;
-      const bool mok = mc < a.Mrows;
-      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-      const f32x4 c_mean = mok ? *(const f32x4*)(a.red_mean + mc) : zero4;
-      const f32x4 c_is = mok ? *(const f32x4*)(a.red_invstd + mc) : zero4;
-      f32x4 zs = one4, zo = zero4, sl = one4;
-      if (prelu && mok) {
-        const f32x4 g = a.red_gamma ? *(const f32x4*)(a.red_gamma + mc) : one4;
-        const f32x4 b = a.red_beta ? *(const f32x4*)(a.red_beta + mc) : zero4;
-        sl = *(const f32x4*)(a.red_slope + mc);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // a round = four channel tiles; per tile the three sums of this lane's 4 channels over its NT pixels, two channels per packed
+    // fp32 instruction; then the transposing fold over the row's 16 pixel lanes (row16_fold16)
+    auto round_red = [&](auto rc, auto full_tag, auto prelu_tag) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      constexpr bool FULL = decltype(full_tag)::value, PRELU = decltype(prelu_tag)::value;
+      float S0[16], S1[16], S2[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          zs[e] = c_is[e] * g[e];
-          zo[e] = b[e] - c_mean[e] * zs[e];
-        }
-      }
-      float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-      const int lchunk = (wm * (BM / WM) + i * 16 + 4 * h) >> 3;     // logical 16-byte chunk of this lane's 4 channels
-      uint2 xr[NT];
+      for (int k = 0; k < 16; ++k) S0[k] = S1[k] = S2[k] = 0.f;
+      static_for<(MT - 4 * r < 4 ? MT - 4 * r : 4)>([&](auto iic) {
+        constexpr int ii = decltype(iic)::value, i = 4 * r + ii;
+        const int mc = mw + i * 16;
+        const bool mok = FULL || mc < a.Mrows;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+        const f32x4 c_mean = mok ? *(const f32x4*)(a.red_mean + mc) : zero4;
+        const f32x4 c_is = mok ? *(const f32x4*)(a.red_invstd + mc) : zero4;
+        f32x4 zs = one4, zo = zero4, sl = one4;
+        if (PRELU && mok) {
+          const f32x4 g = a.red_gamma ? *(const f32x4*)(a.red_gamma + mc) : one4;
+          const f32x4 b = a.red_beta ? *(const f32x4*)(a.red_beta + mc) : zero4;
+          sl = *(const f32x4*)(a.red_slope + mc);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * (BN / WN) + j * 16 + r16;
-        const uint32_t addr = x_base + (uint32_t)(row * (BM * 2) + ((lchunk ^ (row & (XCPR - 1))) << 4) + ((h & 1) << 3));
-        asm volatile("ds_read_b64 %0, %1" : "=v"(xr[j]) : "v"(addr));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);   // nothing that consumes xr may move above the wait
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const uint2 xw = xr[j];
-        const bool ok = full_tile || (pw + j * 16 < P && mok);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t wd = (e >> 1) ? xw.y : xw.x;
-          const float xf = __uint_as_float((e & 1) ? (wd & 0xffff0000u) : (wd << 16));
-          const float dyv = ok ? (float)(__bf16)acc[i][j][e] : 0.f;
-          float dz = dyv;
-          if (prelu) {
-            const float z = xf * zs[e] + zo[e];
-            const bool neg = z <= 0.f;
-            s2[e] += neg ? dyv * z : 0.f;
-            dz = neg ? dyv * sl[e] : dyv;
+          for (int e = 0; e < 4; ++e) {
+            zs[e] = c_is[e] * g[e];
+            zo[e] = b[e] - c_mean[e] * zs[e];
           }
-          s0[e] += dz;
-          s1[e] += dz * (xf - c_mean[e]);
         }
-      }
+        f32x2 s0[2], s1[2], s2[2], mean2[2], zs2[2], zo2[2];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        fold(s0[e], i, e, keep[0]);
-        fold(s1[e] * c_is[e], i, e, keep[1]);
-        fold(s2[e], i, e, keep[2]);
+        for (int g = 0; g < 2; ++g) {
+          s0[g] = s1[g] = s2[g] = (f32x2){0.f, 0.f};
+          mean2[g] = (f32x2){c_mean[2 * g], c_mean[2 * g + 1]};
+          zs2[g] = (f32x2){zs[2 * g], zs[2 * g + 1]};
+          zo2[g] = (f32x2){zo[2 * g], zo[2 * g + 1]};
+        }
+        const int lchunk = (wm * (BM / WM) + i * 16 + 4 * h) >> 3;     // logical 16-byte chunk of this lane's 4 channels
+        uint2 xr[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wn * (BN / WN) + j * 16 + r16;
+          const uint32_t addr = x_base + (uint32_t)(row * (BM * 2) + ((lchunk ^ (row & (XCPR - 1))) << 4) + ((h & 1) << 3));
+          asm volatile("ds_read_b64 %0, %1" : "=v"(xr[j]) : "v"(addr));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);   // nothing that consumes xr may move above the wait
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const bool ok = FULL || (pw + j * 16 < P && mok);
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const uint32_t wd = g ? xr[j].y : xr[j].x;
+            const f32x2 x2 = {__uint_as_float(wd << 16), __uint_as_float(wd & 0xffff0000u)};
+            f32x2 dy2 = {rounded(i, j, 2 * g), rounded(i, j, 2 * g + 1)};
+            if (!ok) dy2 = (f32x2){0.f, 0.f};
+            f32x2 dz2 = dy2;
+            if constexpr (PRELU) {
+              const f32x2 z2 = x2 * zs2[g] + zo2[g];
+              const bool n0 = z2[0] <= 0.f, n1 = z2[1] <= 0.f;
+              const f32x2 t2 = dy2 * z2;
+              s2[g] += (f32x2){n0 ? t2[0] : 0.f, n1 ? t2[1] : 0.f};
+              dz2 = dy2 * (f32x2){n0 ? sl[2 * g] : 1.f, n1 ? sl[2 * g + 1] : 1.f};
+            }
+            s0[g] += dz2;
+            s1[g] += dz2 * (x2 - mean2[g]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          S0[ii * 4 + e] = s0[e >> 1][e & 1];
+          S1[ii * 4 + e] = s1[e >> 1][e & 1] * c_is[e];
+          S2[ii * 4 + e] = s2[e >> 1][e & 1];
+        }
+      });
+      keep[0][r] = row16_fold16(S0, r16);
+      keep[1][r] = row16_fold16(S1, r16);
+      if constexpr (PRELU) keep[2][r] = row16_fold16(S2, r16);
+    };
+    if (!(a.dbg & 8)) {
+      if (full_tile) {
+        if (prelu) static_for<NR>([&](auto rc) { round_red(rc, std::true_type{}, std::true_type{}); });
+        else static_for<NR>([&](auto rc) { round_red(rc, std::true_type{}, std::false_type{}); });
+      } else {
+        if (prelu) static_for<NR>([&](auto rc) { round_red(rc, std::false_type{}, std::true_type{}); });
+        else static_for<NR>([&](auto rc) { round_red(rc, std::false_type{}, std::false_type{}); });
       }
-    });
+    }
     __syncthreads();   // every wave has read its part of the x tile: the sums' scratch below lives in the same LDS stage
     if (!(a.dbg & 16)) flush(std::integral_constant<int, 3>{}, keep, a.red_out);
   }
@@ -1610,8 +1663,11 @@ constexpr int xf_seq(int step, int n) {
 // gaps of tap t + 2 (micro-operations of 2 - 3 VALU, one per gap) and written back in place — and, for passes that keep
 // activations, stored to a_out from the registers (rows of the tile proper only: every row of the tensor is written once).  Pieces
 // are fetched in taps 0..5 only, so the last one is back in LDS before the barrier of tap 8, behind which the new patch is first read.
+#ifndef HW4_REG_ATTR
+#define HW4_REG_ATTR
+#endif
 template <int BM, int NT, int PPW, int DIAG = 0, bool RED = false, int XF = 0>
-__global__ __launch_bounds__(256, 1) void conv_igemm_hw4_kernel(ConvArgs a, int PR, int lead) {
+__global__ __launch_bounds__(256, 1) HW4_REG_ATTR void conv_igemm_hw4_kernel(ConvArgs a, int PR, int lead) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool TRACE = DIAG == 1;
   // BM = 64 (the 64-channel layers): one wave row of 64 channels, NT = 14 pixel tiles per wave — the same 56 accumulator tiles and
@@ -2911,7 +2967,7 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
 int hp8_tile_rows(int Mrows, int C, int H, int W, int Ho, int Wo, int R, int S, int stride, int pad, int P) {
   if (!g_conv_hp8 || !(R == 3 && S == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && H >= 2 && C % 64 == 0)) return 0;
   // (64 rows: the 64-channel layers, one chunk, one-wave-per-SIMD kernel only — "hw4_64")
-  const int bm = (Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : (Mrows == 128 && g_conv_hp8 != 2) ? 128
+  const int bm = (Mrows % 256 == 0 && g_conv_hp8 != 3) ? 256 : ((Mrows == 128 || (Mrows % 128 == 0 && g_conv_hp8 == 3)) && g_conv_hp8 != 2) ? 128
                  : (Mrows == 64 && C == 64 && g_conv_hw4 && g_hw4_64 && g_conv_hp8 == 1) ? 64 : 0;
   if (!bm) return 0;
   const int bn = bm == 256 ? 224 : bm == 128 ? 448 : 896;

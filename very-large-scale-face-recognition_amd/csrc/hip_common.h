@@ -56,6 +56,22 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// Sixteen per-lane values, each to be summed over the 16 lanes of a DPP row: lane r16 = k of the row gets the row sum of v[k].
+// A transposing butterfly — in each of the four exchanges (row_mirror, row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]:
+// the partner differs in bit 3 / 2 / 1 / 0 of r16) a lane keeps the half of its values whose index has ITS bit and adds the
+// partner's copy of them: 8 + 4 + 2 + 1 adds with two selects each (45 VALU) instead of sixteen 4-add row sums and 16 selects.
+__device__ __forceinline__ float row16_fold16(const float (&v)[16], int r16) {
+  const bool b3 = r16 & 8, b2 = r16 & 4, b1 = r16 & 2, b0 = r16 & 1;
+  float w[8], x[4], y[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = (b3 ? v[k + 8] : v[k]) + dpp_mov<0x140>(b3 ? v[k] : v[k + 8]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x[k] = (b2 ? w[k + 4] : w[k]) + dpp_mov<0x141>(b2 ? w[k] : w[k + 4]);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) y[k] = (b1 ? x[k + 2] : x[k]) + dpp_mov<0x4E>(b1 ? x[k] : x[k + 2]);
+  return (b0 ? y[1] : y[0]) + dpp_mov<0xB1>(b0 ? y[0] : y[1]);
+}
+
 // v + the value of lane (lane ^ O), without LDS traffic: v_permlane32_swap / v_permlane16_swap across the
 // 16-lane rows (swap(v, v) returns (own, partner) in one half and (partner, own) in the other, so the sum of
 // the pair is own + partner in every lane), DPP row rotations inside a row.  For O < 16 the rotation adds
