@@ -201,7 +201,7 @@ __device__ __forceinline__ int swz(int row) {
   else return row & 7;
 }
 
-template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED = false, bool XWAIT = false>
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED = false, bool XWAIT = false, bool PLAIN = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
                                               int r16, int h, int tid, float* red_lds, const char* x_lds = nullptr);
 
@@ -381,13 +381,15 @@ __device__ __forceinline__ void lds_read_frags(bf16x8* f, uint32_t addr, std::in
 // atomics) or bf16 output with the fused BatchNorm statistics; red_lds = BM*WN*2 floats of LDS nobody reads.
 // XWAIT (with RED): the caller issued the LDS-DMA of the x tile right before this call instead of under its last k-tile; the
 // output stores above go first and the reduction waits for the tile (and a workgroup barrier) itself.
-template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED, bool XWAIT>
+// PLAIN: the caller never asks for fp32 output, split-K or a parity-class launch (run_igemm keeps those off conv_igemm_hw4_kernel):
+// those paths are not compiled into it.
+template <int BM, int BN, int WM, int WN, int MT, int NT, int NW, bool RED, bool XWAIT, bool PLAIN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT][NT], int m0, int p0, int P, int wm, int wn,
                                               int r16, int h, int tid, float* red_lds, const char* x_lds) {
   // ---- epilogue: lane holds channels m = .. + 4h + e (e = 0..3) of pixel .. + r16
   const int mw = m0 + wm * (BM / WM) + 4 * h;     // + 16 i
   const int pw = p0 + wn * (BN / WN) + r16;       // + 16 j
-  if (a.out_f32) {
+  if (!PLAIN && a.out_f32) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int p = pw + j * 16;
@@ -417,7 +419,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
   // launch — the position (n, 2 h' + ph, 2 w' + pw) of pixel (n, h', w') of the class grid, advanced 32 pixels per pair
   // by carries (one division pair per lane)
   int64_t orow[NT / 2 + 1];
-  if (a.cls) {
+  if (!PLAIN && a.cls) {
     const int ph = (a.cls - 1) >> 1, pwc = (a.cls - 1) & 1;
     const int q = pw + (odd ? 16 : 0);
     const int HWc = a.Ho * a.Wo;
@@ -1663,7 +1665,17 @@ constexpr int xf_seq(int step, int n) {
 // gaps of tap t + 2 (micro-operations of 2 - 3 VALU, one per gap) and written back in place — and, for passes that keep
 // activations, stored to a_out from the registers (rows of the tile proper only: every row of the tensor is written once).  Pieces
 // are fetched in taps 0..5 only, so the last one is back in LDS before the barrier of tap 8, behind which the new patch is first read.
-#ifndef HW4_REG_ATTR
+// VLSFR_HW4_REGS (build option, default 224; 0 = no cap): cap of the kernel's architectural VGPRs; the 224 accumulator registers come on
+// top.  224 -> 448 of a SIMD's 512 registers, which leaves 64 for one wave of another stream's kernel beside it: the plain and PReLU
+// bn_apply kernels of the OTHER chain of a pass (56 / 58 registers) then run on the CUs a convolution occupies instead of only on
+// the 32 it leaves idle (same-box A/B, profiles/r04_hw4_register_cap_ab.txt: step -0.2 ms, the kernel alone -0.6 %; the epilogue is
+// written to fit — phases, PLAIN, laundered lane coordinates — so that the cap costs no scratch).
+#ifndef VLSFR_HW4_REGS
+#define VLSFR_HW4_REGS 224
+#endif
+#if VLSFR_HW4_REGS > 0
+#define HW4_REG_ATTR __attribute__((amdgpu_waves_per_eu(1, 2), amdgpu_num_vgpr(VLSFR_HW4_REGS)))
+#else
 #define HW4_REG_ATTR
 #endif
 template <int BM, int NT, int PPW, int DIAG = 0, bool RED = false, int XF = 0>
@@ -2156,7 +2168,11 @@ __global__ __launch_bounds__(256, 1) HW4_REG_ATTR void conv_igemm_hw4_kernel(Con
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_rx, (lds_void_t*)(smem + (wave * XI + i) * 1024), 16, off, 0, 0, 0);
     }
   }
-  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, RED, RED>(a, acc, m0, p0, P, wm, wn, r16, h, tid, (float*)smem, smem);
+  // (the lane coordinates are laundered through an empty asm: otherwise the compiler keeps per-lane pixel indices of the prologue
+  // alive across the whole loop for the partial-tile path of the epilogue — registers the loop has none to spare of)
+  int tid_e = tid;
+  asm volatile("" : "+v"(tid_e));
+  conv_epilogue<BM, BN, WM, WN, MT, NT, NW, RED, RED, true>(a, acc, m0, p0, P, wm, wn, tid_e & 15, (tid_e & 63) >> 4, tid_e, (float*)smem, smem);
   if constexpr (TRACE) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the stores and atomics of this wave have been acknowledged
     if (tr_on && lane == 0) __builtin_nontemporal_store((long long)__builtin_amdgcn_s_memrealtime(), a.trace + 131);
