@@ -672,10 +672,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[MT
         for (int j = 0; j < NT; ++j) {
           const int row = wn * (BN / WN) + j * 16 + r16;
           const uint32_t addr = x_base + (uint32_t)(row * (BM * 2) + ((lchunk ^ (row & (XCPR - 1))) << 4) + ((h & 1) << 3));
-          asm volatile("ds_read_b64 %0, %1" : "=v"(xr[j]) : "v"(addr));
+          // (a plain LDS load, NOT an inline-asm ds_read with a wait further down: under register pressure the compiler copies an
+          // asm statement's outputs elsewhere right behind the statement — before the data has arrived, which it cannot know)
+          xr[j] = *(const __attribute__((address_space(3))) uint2*)(uintptr_t)addr;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);   // nothing that consumes xr may move above the wait
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const bool ok = FULL || (pw + j * 16 < P && mok);
