@@ -115,6 +115,7 @@ int g_wgrad_slabs = 0;       // "wgrad_slabs": 1 = split-K slices to workspace s
 int g_wgrad_round_up = 0;    // "wgrad_round_up": 1 = round the slice count up (may exceed wgrad_target_wgs), the round-1 rule
 int g_wgrad_target = 512;    // "wgrad_target_wgs": workgroups the pixel range of the weight gradient is split into (one round of 2 per CU;
                              // fewer splits = fewer fp32 atomics: 384 measured best end to end, 1024 best for the register-staged kernel)
+int g_deep_ring = 0;            // "conv_deep_ring": 4-stage LDS ring of the default 128 x 128 / 64 x 128 tiles where a launch has at most one workgroup per CU (1), everywhere (2)
 int g_small_tile_wgs = 0;     // "small_tile_wgs": below this many 128 x 128 workgroups a convolution runs on 64 x 128 tiles (0: never)
 int g_dgrad_classes = 1;     // "dgrad_classes": stride-2 input gradients as four parity-class launches (ConvArgs::cls)
 int g_xcd_map = 1;          // "xcd_map": 1 = XCD-major workgroup order in the LDS-DMA convolution / weight-gradient kernels (xcd_major_id)
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(NW * 64, ((NW == 4 && BM * BN >= 256 * 128) || (NW 
   // Rows are the output rows of the tile: consecutive pixels, or (parity-class launch) the stride-2 positions.
   auto issue_x = [&]() {
     if constexpr (RED) {
-      static_assert(NST == 2 && !PP && !SWP && BM * BN * 2 <= (BM + BN) * BK * 2, "RED: the x tile takes the spare stage of the 2-stage ring");
+      static_assert(NST >= 2 && !PP && !SWP && BM * BN * 2 <= (BM + BN) * BK * 2, "RED: the x tile takes the stage tile nk would have taken (free during the last k-tile)");
       constexpr int XRB = BM * 2;                 // x row bytes in LDS
       constexpr int XCPR = XRB / 16;              // chunks per row
       constexpr int XRPI = 1024 / XRB;            // rows per DMA instruction
@@ -3037,6 +3038,8 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
     return fail(VLSFR_EINVAL, "conv_igemm: the fused input BatchNorm needs conv_igemm_hw4_kernel (vlsfr_conv2d_fwd_bnin_supported)");
   // (one round of one tile per CU: the tile count over BOTH grid dimensions is bounded by the 256 CUs — 512 output channels at
   // >= 33 024 pixels would be two rounds, the case the 128 x 128 tiles win)
+  const long wg_here = (a.Mrows >= 128 && wg_big >= g_small_tile_wgs) ? wg_big : (long)((P + 127) / 128) * ((a.Mrows + 63) / 64) * a.splitk;
+  const bool deep_ring = g_deep_ring && (g_deep_ring == 2 || wg_here <= 256);
   const bool tile256_here = !hp8_bm && glds_ok && !halo_here && variant_default && g_tile256 && a.Mrows % 256 == 0 && !a.tap_mask && P >= 256 * g_tile256_min &&
                             (long)(a.Mrows / 256) * ((P + 255) / 256) <= 256 && !(a.red_x && g_tile256 == 2) && !g_bnred_all && a.splitk == 1;
   const bool red_here = !hp8_bm && glds_ok && !halo_here && variant_default && !tile256_here && a.red_x && !a.out_f32 && a.splitk == 1 &&
@@ -3113,9 +3116,16 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
       // reduction kernel" on the 128 x 128 tiles of the stride-1 layers (128 / 256 / 512 channels: 4 - 9 us saved of 20 - 30)
       // and loses on the 64-channel layers (6 - 12 tile rounds per launch: the epilogue is paid per tile) and on the four
       // parity-class launches of a stride-2 layer; "bnred_all" = 1 forces it everywhere (tests)
-      rc = big ? launch_igemm_glds<128, 128, 64, 2, 4, false, false, true>(a, P, st)
-               : launch_igemm_glds<64, 128, 64, 2, 4, false, false, true>(a, P, st);
+      if (deep_ring) rc = big ? launch_igemm_glds<128, 128, 64, 4, 4, false, false, true>(a, P, st)
+                              : launch_igemm_glds<64, 128, 64, 4, 4, false, false, true>(a, P, st);
+      else rc = big ? launch_igemm_glds<128, 128, 64, 2, 4, false, false, true>(a, P, st)
+                    : launch_igemm_glds<64, 128, 64, 2, 4, false, false, true>(a, P, st);
       if (red_done) *red_done = true;
+    } else if (deep_ring) {
+      // at most one workgroup per CU (small batches: 196 tiles on the 256-channel 14 x 14 layers of batch 64, 100 on the
+      // 512-channel 7 x 7 ones): no second workgroup hides the LDS-DMA latency, and one k-tile of 32 MFMAs per wave (~0.25 us)
+      // is far shorter than it — a 4-stage ring (three k-tiles in flight, 128 KB of LDS) instead of the 2-stage one
+      rc = big ? launch_igemm_glds<128, 128, 64, 4>(a, P, st) : launch_igemm_glds<64, 128, 64, 4>(a, P, st);
     } else rc = big ? launch_igemm_glds<128, 128, 64, 2>(a, P, st) : launch_igemm_glds<64, 128, 64, 2>(a, P, st);
     if (rc != VLSFR_OK) return rc;
   } else if (a.Mrows >= 128 && wg_big >= 192) launch_igemm<128, 128>(a, P, st);
@@ -3163,6 +3173,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "dw_wgrad_blocks")) {
     vlsfr::g_dw_wgrad_blocks = value > 0 ? value : 256;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "conv_deep_ring")) {
+    g_deep_ring = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "conv_halo")) {
