@@ -456,10 +456,12 @@ def test_conv_halo_patch_four_phase_kernel_is_bit_identical(cin, cout, hw, N):
     outs = {}
     try:
         setopt(b"hp8_fill", 0)                   # take the kernels whatever share of the chip their tiles fill
-        # 2: conv_igemm_hw4_kernel (one wave per SIMD, software-pipelined: the default), 1: conv_igemm_hp8_kernel (four phases), 0: round-3 kernels
-        for mode in (2, 1, 0):
+        # 3: conv_igemm_hw4_kernel on 256 x 208 tiles wherever they fit (52 accumulator tiles per wave), 2: the same kernel on 256 x 224
+        # tiles (one wave per SIMD, software-pipelined), 1: conv_igemm_hp8_kernel (four phases), 0: round-3 kernels
+        for mode in (3, 2, 1, 0):
             setopt(b"conv_hp8", 1 if mode else 0)
-            setopt(b"conv_hw4", 1 if mode == 2 else 0)
+            setopt(b"conv_hw4", 1 if mode >= 2 else 0)
+            setopt(b"hw4_208", 2 if mode == 3 else 0)
             stats = ops.new_sums(cout, "cuda")
             outs[mode] = (ops.conv2d_fwd(x, wb, big, stats=stats), ops.conv2d_dgrad(dy, wT, big), stats.sum(0))
             if mode:                             # LDS hand-offs that were wrong would be timing-dependent: the same launch, repeatedly
@@ -468,7 +470,11 @@ def test_conv_halo_patch_four_phase_kernel_is_bit_identical(cin, cout, hw, N):
     finally:
         setopt(b"conv_hp8", 1)
         setopt(b"conv_hw4", 1)
+        setopt(b"hw4_208", 0)
         setopt(b"hp8_fill", 80)
+    assert torch.equal(outs[3][0], outs[0][0]) and torch.equal(outs[3][1], outs[0][1])
+    close(outs[3][2][0], outs[0][2][0].cpu(), 1e-6)
+    close(outs[3][2][1], outs[0][2][1].cpu(), 1e-6)
     assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[2][1], outs[0][1])
     assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
     for s0 in sorted({0, min(N // 2, N - n), N - n}):       # and the small-batch kernel on slices (a convolution is independent per image)
@@ -755,10 +761,13 @@ def test_dgrad_bnred_in_the_one_wave_per_simd_kernel(cin, cout, hw, N, prelu):
     setopt(b"hp8_fill", 0)
     try:
         _check_bnred(cin, cout, 3, 1, hw, N, prelu)
+        setopt(b"hw4_208", 2)                    # ... and on the 256 x 208 tiles where they fit
+        _check_bnred(cin, cout, 3, 1, hw, N, prelu)
         setopt(b"hw4_red", 0)                 # and with the stand-alone kernel behind the same convolution kernel
         _check_bnred(cin, cout, 3, 1, hw, N, prelu)
     finally:
         setopt(b"hw4_red", 1)
+        setopt(b"hw4_208", 0)
         setopt(b"hp8_fill", 80)
 
 

@@ -128,6 +128,7 @@ int g_conv_bnin = 0;         // "conv_bnin": vlsfr_conv2d_fwd_bnin (BatchNorm / 
                              // 79.5 us (a_out written) fused on the 256-channel layers, 84.9 against 92.4 / 102.1 on the 128-channel ones; the step
                              // 87.0 against 83.5 ms: with ONE wave per SIMD the transform's ~200 extra instructions per k-tile sit in the MFMA wave's own
                              // issue slots, and bn_apply was half hidden beside the other stream's convolutions anyway
+int g_hw4_208 = 0;           // "hw4_208": 256 x 208 tiles (conv_igemm_hw4_kernel<256, 13>) where they need no more rounds than 256 x 224 (1), wherever they fit (2).  OFF: the kernel alone is no faster (57.6 against 58.0 us) and the STEP is 2.5 ms slower — 242 workgroups leave 14 CUs instead of 32 to the other chain's BatchNorm kernels (profiles/r04_hw4_208_tiles_ab.txt)
 int g_hw4_64 = 1;            // "hw4_64": the 64-channel 3x3 / stride-1 layers on conv_igemm_hw4_kernel<64, 14> (64 x 896 tiles) instead of conv_igemm_halo_kernel
 int g_hw4_red = 1;           // "hw4_red": conv_igemm_hw4_kernel accumulates the BatchNorm-backward reduction in its epilogue when asked to (0: stand-alone kernel)
 int g_hp8_fill = 80;         // "hp8_fill": least percentage of the workgroup slots of its rounds (256 per round) that conv_igemm_hp8_kernel must fill
@@ -1685,7 +1686,8 @@ __global__ __launch_bounds__(256, 1) HW4_REG_ATTR void conv_igemm_hw4_kernel(Con
   constexpr bool TRACE = DIAG == 1;
   // BM = 64 (the 64-channel layers): one wave row of 64 channels, NT = 14 pixel tiles per wave — the same 56 accumulator tiles and
   // MFMA gaps per step; those layers have ONE 64-channel chunk, so their (large: 896 + 2 W rows) patch is fetched once, in the prologue
-  constexpr int WROWS = BM >= 128 ? 128 : 64;
+  // NT = 13 (the 208-pixel tiles): 64-row waves, 4 x 13 = 52 accumulator tiles — 256 x 208 tiles (four wave rows, one pixel range)
+  constexpr int WROWS = (BM >= 128 && NT != 13) ? 128 : 64;
   constexpr int BK = 64, NW = 4, WM = BM / WROWS, WN = NW / WM, MT = WROWS / 16;
   constexpr int BN = WN * NT * 16;
   constexpr int RSB = 128;
@@ -1693,10 +1695,10 @@ __global__ __launch_bounds__(256, 1) HW4_REG_ATTR void conv_igemm_hw4_kernel(Con
   constexpr int PA = BM / 8 / NW;            // LDS-DMA pieces of a weight tile per wave (8 rows each): 8 or 4
   constexpr int NMF = MT * NT;               // MFMAs per step
   constexpr int OOB = (int)0x80000000;
-  static_assert((BM == 256 || BM == 128 || BM == 64) && MT * NT == 56 && PPW >= 1 && PPW <= 3 && !(XF && RED) && !(XF && BM == 64), "tile");
+  static_assert((BM == 256 || BM == 128 || BM == 64) && (MT * NT == 56 || MT * NT == 52) && PPW >= 1 && PPW <= 3 && !(XF && RED) && !(XF && BM == 64), "tile");
   constexpr int PT = XF ? 6 : 8;             // taps of a chunk in which pieces of the next patch are fetched
   constexpr int XMP = XF == 2 ? 22 : XF == 1 ? 14 : 0;   // micro-operations of the transform of one piece
-  static_assert(XMP * PPW <= 120 && NMF == 56, "the transform of a tap's pieces fits its slots (xf_seq is laid out for 56 gaps per step)");
+  static_assert(XMP * PPW <= 120 && (NMF == 56 || XF == 0), "the transform of a tap's pieces fits its slots (xf_seq is laid out for 56 gaps per step)");
   constexpr int DSTEP = BM == 256 ? 5 : (PPW == 3 ? 7 : 8);   // MFMA gaps between two LDS-DMA pieces of the second step
   static_assert((PA + PPW - 1) * DSTEP < NMF && (PA + PPW - 1) * DSTEP + 6 < NMF && PA + PPW + MT + NT + 5 <= NMF && MT + NT + 4 + 2 * NT + 3 * PPW <= NMF, "the side operations of a step fit its MFMA gaps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2922,7 +2924,7 @@ int launch_igemm_hp8(const ConvArgs& a, int P, hipStream_t st) {
 
 template <int BM, int NT>
 int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
-  constexpr int WROWS = BM >= 128 ? 128 : 64;
+  constexpr int WROWS = (BM >= 128 && NT != 13) ? 128 : 64;
   constexpr int BN = (4 / (BM / WROWS)) * NT * 16;
   const int lead = hp8_lead(BN, a.W), PR = hp8_patch_rows(BN, a.W);
   int lds = hp8_lds_bytes(BM, BN, a.W, a.C > 64 ? 2 : 1) + 1024;   // + the dump area of the LDS-DMA pieces that have nothing to fetch
@@ -2943,10 +2945,16 @@ int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
   // pieces of the next patch per wave and tap: 8 x 4 x PPW slots per chunk, 6 x 4 x PPW with the input transform (XF)
   constexpr int XPPW = BM == 256 ? 2 : 3;
   if (a.xf_scale && PR / 8 > 24 * XPPW) return fail(VLSFR_EINVAL, "conv_igemm_hw4: patch of %d rows does not fit the transform's piece slots", PR);
-  auto kern = a.xf_scale ? (a.xf_slope ? conv_igemm_hw4_kernel<BM, NT, XPPW, 0, false, 2> : conv_igemm_hw4_kernel<BM, NT, XPPW, 0, false, 1>)
-              : red      ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0, true> : conv_igemm_hw4_kernel<BM, NT, 1, 0, true>)
-              : a.trace  ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
-                         : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
+  void (*kern)(ConvArgs, int, int);
+  if constexpr (NT == 13) {   // 208-pixel tiles: one piece of the next patch per wave and tap (patches of at most 256 rows), no input transform
+    if (a.xf_scale || PR > 256) return fail(VLSFR_EINVAL, "conv_igemm_hw4: the 208-pixel tile takes patches of at most 256 rows and no input transform");
+    kern = red ? conv_igemm_hw4_kernel<BM, NT, 1, 0, true> : conv_igemm_hw4_kernel<BM, NT, 1, 0, false>;
+  } else {
+    kern = a.xf_scale ? (a.xf_slope ? conv_igemm_hw4_kernel<BM, NT, XPPW, 0, false, 2> : conv_igemm_hw4_kernel<BM, NT, XPPW, 0, false, 1>)
+           : red      ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0, true> : conv_igemm_hw4_kernel<BM, NT, 1, 0, true>)
+           : a.trace  ? (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 1> : conv_igemm_hw4_kernel<BM, NT, 1, 1>)
+                      : (PR > 256 ? conv_igemm_hw4_kernel<BM, NT, 2, 0> : conv_igemm_hw4_kernel<BM, NT, 1, 0>);
+  }
   if (int rc = ensure_dynamic_lds((const void*)kern, lds, "conv_igemm_hw4")) return rc;
   dim3 grid((P + BN - 1) / BN, a.Mrows / BM, 1);
   ConvArgs b = a;
@@ -2981,6 +2989,15 @@ void launch_igemm(const ConvArgs& a, int P, hipStream_t st) {
 
 // Rows of the halo-patch kernels' tile (256 / 128) for this convolution, or 0: 3x3 / stride 1 / pad 1, 256-row tiles x 224 pixels or
 // 128-row tiles x 448 pixels, where those tiles fill at least g_hp8_fill % of the workgroup slots of their rounds
+// ... and whether the 256-row tile should be the 208-pixel one (conv_igemm_hw4_kernel<256, 13>: 52 accumulator tiles per wave): where
+// that needs no more rounds of workgroups than the 224-pixel tile, every workgroup does 13 / 14 of the work (ir100 at batch 256, the
+// 256-channel 14 x 14 layers: 242 workgroups on the 256 CUs instead of 224)
+bool hw4_wants_208(int Mrows, int C, int W, int P, bool xf) {
+  if (!g_hw4_208 || !g_conv_hw4 || xf || Mrows % 256 != 0 || hp8_patch_rows(208, W) > 256) return false;
+  const long t7 = (long)((P + 223) / 224) * (Mrows / 256), t13 = (long)((P + 207) / 208) * (Mrows / 256);
+  return g_hw4_208 == 2 || ((t13 + 255) / 256) * 208 < ((t7 + 255) / 256) * 224;
+}
+
 int hp8_tile_rows(int Mrows, int C, int H, int W, int Ho, int Wo, int R, int S, int stride, int pad, int P) {
   if (!g_conv_hp8 || !(R == 3 && S == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W && H >= 2 && C % 64 == 0)) return 0;
   // (64 rows: the 64-channel layers, one chunk, one-wave-per-SIMD kernel only — "hw4_64")
@@ -3056,7 +3073,9 @@ int run_igemm(ConvArgs a, hipStream_t st, bool* red_done = nullptr) {
     if (rc != VLSFR_OK) return rc;
   } else if (hp8_bm) {
     const int rc = hp8_bm == 64 ? launch_igemm_hw4<64, 14>(a, P, st, hw4_red)
-                   : g_conv_hw4 ? (hp8_bm == 256 ? launch_igemm_hw4<256, 7>(a, P, st, hw4_red) : launch_igemm_hw4<128, 7>(a, P, st, hw4_red))
+                   : g_conv_hw4 ? (hp8_bm == 256 ? (hw4_wants_208(a.Mrows, a.C, a.W, P, a.xf_scale != nullptr) ? launch_igemm_hw4<256, 13>(a, P, st, hw4_red)
+                                                                                                                  : launch_igemm_hw4<256, 7>(a, P, st, hw4_red))
+                                                  : launch_igemm_hw4<128, 7>(a, P, st, hw4_red))
                               : (hp8_bm == 256 ? launch_igemm_hp8<256, 7>(a, P, st) : launch_igemm_hp8<128, 7>(a, P, st));
     if (hw4_red && red_done) *red_done = true;
     if (rc != VLSFR_OK) return rc;
@@ -3173,6 +3192,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "dw_wgrad_blocks")) {
     vlsfr::g_dw_wgrad_blocks = value > 0 ? value : 256;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "hw4_208")) {
+    g_hw4_208 = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "conv_deep_ring")) {
