@@ -97,6 +97,8 @@ def parse():
                     "(parallel.RehearsalDist).  Config C4: --rehearse-world 8 --identities 104857600 --batch 64")
     ap.add_argument("--head-dtype", default="bf16", choices=["bf16", "fp8"], help="fp8: the e4m3 sweep of csrc/head8.hip (config C5's "
                     "precision for the class matmul; the backbone stays bf16)")
+    ap.add_argument("--cu-reserve", type=int, default=0, help="experiment: run the probe chain and the gallery / second-backward chain on CU-masked "
+                    "streams that each leave this many CUs (a multiple of 8) to the other chain")
     ap.add_argument("--phases", action="store_true", help="diagnostic: print the forward / backward / update split to stderr")
     ap.add_argument("--timed-profile", action="store_true", help="per-launch HIP events inside the timed region itself (they cost "
                     "~1.5 %% of the step: by default the K timed steps run clean and are REPEATED with the events on)")
@@ -256,6 +258,14 @@ def main():
             if hasattr(net, "use_graphs"):
                 net.use_graphs = bool(on)
     set_graphs(args.graphs)
+    if args.cu_reserve:
+        from vlsfr_amd.parallel import cu_masked_stream
+        main_m = cu_masked_stream(dev, args.cu_reserve, low=True)
+        side_m = cu_masked_stream(dev, args.cu_reserve, low=False)
+        main_m.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_m)
+        model.__dict__['_side_stream'] = side_m
+        model.probe_net._bwd_stream = side_m
     if args.serial:
         model.__dict__['concurrent_streams'] = False
         model.probe_net.concurrent_backward = False

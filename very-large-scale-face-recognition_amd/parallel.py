@@ -49,6 +49,36 @@ def warm_stream_pool(device, n=4):
     torch.cuda.synchronize(device)
 
 
+_masked_streams = []   # (keeps the HIP stream handles of cu_masked_stream alive)
+
+
+def cu_masked_stream(device, reserve, low):
+    """A HIP stream whose kernels may run on all CUs but `reserve` of them (hipExtStreamCreateWithCUMask), as a torch stream.
+    Mask bit b is CU b / 8 of XCD b % 8 on the 8-XCD parts, so clearing the lowest (low=True) or the highest `reserve` bits takes
+    reserve / 8 CUs out of every XCD.  Two chains that run side by side get complementary masks: each has CUs the other chain's
+    convolutions never occupy, for its BatchNorm kernels (experiment: bench.py --cu-reserve)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    props_cus = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (props_cus + 31) // 32
+    bits = [1] * props_cus
+    rng = range(0, reserve) if low else range(props_cus - reserve, props_cus)
+    for b in rng:
+        bits[b] = 0
+    mask = (ctypes.c_uint32 * words)()
+    for b, v in enumerate(bits):
+        if v:
+            mask[b // 32] |= (1 << (b % 32))
+    st = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    ext = torch.cuda.ExternalStream(st.value, device=device)
+    _masked_streams.append((st, ext))
+    return ext
+
+
 class Comm(object):
     """The collectives of the step on device tensors.  Backend "nccl" (= RCCL on ROCm) runs them in place; under
     gloo (CPU tests, the 2-rank rehearsal on a 1-GPU box) the same calls stage through host memory."""
