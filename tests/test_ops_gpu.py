@@ -489,6 +489,67 @@ def test_conv_halo_patch_four_phase_kernel_is_bit_identical(cin, cout, hw, N):
     close(outs[1][0][:n].permute(0, 3, 1, 2), bf(y_ref), 1e-2)
 
 
+# The 4-stage LDS ring of the default tiles (option conv_deep_ring: launches of at most one workgroup per CU, small batches) changes
+# when a k-tile is fetched, not what is accumulated in which order: bit-identical to the 2-stage ring, forward (with statistics),
+# input gradient, and the input gradient that carries the BatchNorm-backward reduction.
+@pytest.mark.parametrize("cin,cout,k,stride,hw,N", [(256, 256, 3, 1, 14, 16), (512, 512, 3, 1, 7, 24), (256, 512, 3, 2, 14, 8),
+                                                    (128, 256, 1, 2, 28, 6), (64, 128, 3, 1, 28, 3)],
+                         ids=["256ch-14", "512ch-7", "stride2", "1x1-stride2", "64to128"])
+def test_conv_deep_ring_is_bit_identical(cin, cout, k, stride, hw, N):
+    import ctypes
+    from vlsfr_amd import ops, _lib
+    pad = k // 2
+    ho = ops.out_hw(hw, k, stride, pad)
+    gen = torch.Generator(device="cuda").manual_seed(3 + hw + cin + k)
+    x = torch.randn(N, hw, hw, cin, device="cuda", generator=gen).to(torch.bfloat16)
+    dy = torch.randn(N, ho, ho, cout, device="cuda", generator=gen).to(torch.bfloat16)
+    w = (torch.randn(cout, k, k, cin, device="cuda", generator=gen) * 0.05).contiguous()
+    wb, wT = ops.cast_weight(w, cout, k * k, cin)
+    d = ops.ConvDesc(N, hw, hw, cin, cout, k, k, stride, pad)
+    M = N * hw * hw
+    xf = x.float().reshape(M, cin)
+    mean, invstd = xf.mean(0).contiguous(), (1.0 / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)).contiguous()
+    gamma, beta = torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda")
+    slope = torch.full((cin,), 0.25, device="cuda")
+    setopt = lambda name, v: _lib.lib().vlsfr_set_option(name, ctypes.c_int32(v))
+    outs = {}
+    try:
+        for ring in (0, 2):
+            setopt(b"conv_deep_ring", ring)
+            stats = ops.new_sums(cout, "cuda")
+            y = ops.conv2d_fwd(x, wb, d, stats=stats)
+            dx, red = ops.conv2d_dgrad_bnred(dy, wT, d, x, mean, invstd, gamma, beta, slope)
+            outs[ring] = (y, ops.conv2d_dgrad(dy, wT, d), dx, stats.sum(0), red.double().sum(0))
+    finally:
+        setopt(b"conv_deep_ring", 0)
+    for i in range(3):
+        assert torch.equal(outs[2][i], outs[0][i])
+    close(outs[2][3][0], outs[0][3][0].cpu(), 1e-6)
+    close(outs[2][3][1], outs[0][3][1].cpu(), 1e-6)
+    scale = outs[0][4].abs().max(1, keepdim=True).values + 1e-12
+    close(outs[2][4] / scale, (outs[0][4] / scale).cpu(), 1e-4)
+
+
+def test_cu_masked_stream_runs_kernels():
+    """parallel.cu_masked_stream (bench.py --cu-reserve): a convolution issued on a stream that may use all CUs but 32 gives the
+    result of the default stream."""
+    from vlsfr_amd import ops
+    from vlsfr_amd.parallel import cu_masked_stream
+    torch.manual_seed(5)
+    x = torch.randn(8, 14, 14, 256, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(256, 3, 3, 256, device="cuda") * 0.05).contiguous()
+    wb, _ = ops.cast_weight(w, 256, 9, 256)
+    d = ops.ConvDesc(8, 14, 14, 256, 256, 3, 3, 1, 1)
+    ref = ops.conv2d_fwd(x, wb, d)
+    torch.cuda.synchronize()
+    for low in (True, False):
+        st = cu_masked_stream(torch.device("cuda", torch.cuda.current_device()), 32, low)
+        with torch.cuda.stream(st):
+            y = ops.conv2d_fwd(x, wb, d)
+        st.synchronize()
+        assert torch.equal(y, ref)
+
+
 # ---- operators of the torchvision-style ResNet (reference model/resnet_std.py) ---------------------------------
 def test_stem7_im2col_matches_conv():
     from vlsfr_amd import ops
