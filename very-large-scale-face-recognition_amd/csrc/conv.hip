@@ -128,6 +128,7 @@ int g_conv_bnin = 0;         // "conv_bnin": vlsfr_conv2d_fwd_bnin (BatchNorm / 
                              // 79.5 us (a_out written) fused on the 256-channel layers, 84.9 against 92.4 / 102.1 on the 128-channel ones; the step
                              // 87.0 against 83.5 ms: with ONE wave per SIMD the transform's ~200 extra instructions per k-tile sit in the MFMA wave's own
                              // issue slots, and bn_apply was half hidden beside the other stream's convolutions anyway
+int g_hw4_rounds = 0;        // "hw4_rounds": multi-round launches of conv_igemm_hw4_kernel go out round by round with the tiles dealt evenly (launch_igemm_hw4)
 int g_hw4_208 = 0;           // "hw4_208": 256 x 208 tiles (conv_igemm_hw4_kernel<256, 13>) where they need no more rounds than 256 x 224 (1), wherever they fit (2).  OFF: the kernel alone is no faster (57.6 against 58.0 us) and the STEP is 2.5 ms slower — 242 workgroups leave 14 CUs instead of 32 to the other chain's BatchNorm kernels (profiles/r04_hw4_208_tiles_ab.txt)
 int g_hw4_64 = 1;            // "hw4_64": the 64-channel 3x3 / stride-1 layers on conv_igemm_hw4_kernel<64, 14> (64 x 896 tiles) instead of conv_igemm_halo_kernel
 int g_hw4_red = 1;           // "hw4_red": conv_igemm_hw4_kernel accumulates the BatchNorm-backward reduction in its epilogue when asked to (0: stand-alone kernel)
@@ -155,6 +156,7 @@ struct ConvArgs {
   double* stats;     // optional [VLSFR_BN_REPL][2][Mrows] float64 BatchNorm statistics (sum, sum of squares) of the rounded output
   long long* trace;  // diagnostics: per-phase clock stamps of waves 0 and 4 of one workgroup (vlsfr_conv_trace), or nullptr
   int gx = 0, gy = 0, xcd = 0;   // xcd != 0: launched as a 1-D grid of gx * gy * splitk workgroups in XCD-major order (xcd_major_id)
+  int tile0 = 0;                 // conv_igemm_hw4_kernel launched round by round ("hw4_rounds"): logical id of this launch's workgroup 0
   // Parity-class launch of a stride-2 input gradient (vlsfr_conv2d_dgrad): the input positions (2 h' + ph, 2 w' + pw) of one
   // parity class see a stride-1 convolution of dY with the 1, 2 or 4 filter taps of matching parity, so each class is run
   // as a forward-mode gather over the dY grid with a subset of a virtual 3 x 3 (or 1 x 1) filter and its rows scattered
@@ -1714,7 +1716,7 @@ __global__ __launch_bounds__(256, 1) HW4_REG_ATTR void conv_igemm_hw4_kernel(Con
   const int K = 9 * a.C;
   int bx = blockIdx.x, by = blockIdx.y;
   if (a.xcd) {
-    const int g = xcd_major_id(blockIdx.x, a.gx * a.gy);
+    const int g = xcd_major_id(blockIdx.x + a.tile0, a.gx * a.gy);
     bx = g / a.gy;
     by = g - bx * a.gy;
   }
@@ -2963,6 +2965,17 @@ int launch_igemm_hw4(const ConvArgs& a, int P, hipStream_t st, bool red) {
   b.gy = (int)grid.y;
   b.xcd = g_xcd_map && nwg >= 16 && nwg < (1u << 30);
   if (b.xcd) grid = dim3((unsigned)nwg, 1, 1);
+  // "hw4_rounds": a launch of two or three rounds of workgroups goes out round by round, the tiles dealt evenly (448 tiles of the
+  // 128-channel 28 x 28 layers = 224 + 224 instead of 256 + 192): the same number of rounds, but 32 CUs stay free for the other
+  // chain's BatchNorm kernels in every round
+  if (b.xcd && g_hw4_rounds && nwg > 256 && nwg <= 3 * 256) {
+    const size_t rounds = (nwg + 255) / 256, per = (((nwg + rounds - 1) / rounds) + 7) & ~(size_t)7;
+    for (size_t t0 = 0; t0 < nwg; t0 += per) {
+      b.tile0 = (int)t0;
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nwg - t0 < per ? nwg - t0 : per), 1, 1), dim3(256), lds, st, b, PR, lead);
+    }
+    return VLSFR_OK;
+  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b, PR, lead);
   return VLSFR_OK;
   }
@@ -3192,6 +3205,10 @@ int vlsfr_set_option(const char* name, int32_t value) {
   }
   if (name && !strcmp(name, "dw_wgrad_blocks")) {
     vlsfr::g_dw_wgrad_blocks = value > 0 ? value : 256;
+    return VLSFR_OK;
+  }
+  if (name && !strcmp(name, "hw4_rounds")) {
+    g_hw4_rounds = value;
     return VLSFR_OK;
   }
   if (name && !strcmp(name, "hw4_208")) {
